@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by EXECUTING the reference.
+
+Runs only in the build container (needs /root/reference, CPU torch).  Nothing of
+the reference is copied: the script imports its modules, feeds them seeded
+synthetic tensors and stores inputs + outputs as small .npz files.  The GPU box
+never runs this script; tests there read the committed .npz files.
+
+Reference entry points exercised (file:line relative to /root/reference):
+  models/unet.py:6-22 (DoubleConv), :24-90 (UNet3D)
+  models/unet_dann.py:65-98 (forward with return_features)
+  utils/metrics.py:14-40,65-129,137-190 (losses and metrics)
+  train_unet.py:178-205 (get_loss_fn variants)
+  train_dann.py:22-49 (GradientReversal, DomainDiscriminator), :268-285 (DANN step math)
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    # utils/dataloader.py needs nibabel + monai for FILE I/O only; they are not
+    # installed (ordinary ModuleNotFoundError).  Empty stand-in modules let
+    # train_unet.py / train_dann.py import so their pure-torch symbols are usable.
+    for name in ("nibabel", "monai", "monai.transforms"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    class _AnyTransform:
+        def __init__(self, *a, **k):
+            pass
+
+    mt = sys.modules["monai.transforms"]
+    mt.__getattr__ = lambda name: _AnyTransform   # PEP 562: any transform name resolves to a dummy
+    import models.unet as ref_unet
+    import models.unet_dann as ref_unet_dann
+    import utils.metrics as ref_metrics
+    import train_unet as ref_train_unet
+    import train_dann as ref_train_dann
+    return ref_unet, ref_unet_dann, ref_metrics, ref_train_unet, ref_train_dann
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def synth(n, s, seed, blocky=False, dims=None):
+    """SURVEY §8(d) synthetic inputs: seeded randn image, uniform or blocky labels."""
+    g = torch.Generator().manual_seed(seed)
+    d, h, w = dims if dims else (s, s, s)
+    x = torch.randn(n, 1, d, h, w, generator=g)
+    y = torch.randint(0, 4, (n, 1, d, h, w), generator=g)
+    if blocky:
+        zz, yy, xx = torch.meshgrid(torch.arange(d), torch.arange(h), torch.arange(w), indexing="ij")
+        lab = ((zz // max(d // 4, 1)) + (yy // max(h // 4, 1)) + (xx // max(w // 4, 1))) % 4
+        y = lab[None, None].expand(n, 1, d, h, w).contiguous().long()
+        x = y.float() / 3.0 + 0.1 * x
+    return x, y
+
+
+def param_digest(sd):
+    """Per-tensor (sum, abs-sum) — lets a test prove its seeded init equals the reference's."""
+    keys = sorted(sd.keys())
+    dig = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys])
+    return keys, dig
+
+
+def gen_small_unet(ref_unet, ref_metrics, out):
+    """Complete fixture (all weights, all grads) for a small non-cubic, odd-channel net."""
+    torch.manual_seed(7)
+    m = ref_unet.UNet3D(in_channels=2, out_channels=3, features=[4, 8], dropout_rate=0.0)
+    # make BN affine/bias non-trivial so parity exercises them
+    g = torch.Generator().manual_seed(71)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 2, 8, 12, 4, generator=g)
+    y = torch.randint(0, 3, (2, 1, 8, 12, 4), generator=g)
+    m.train()
+    logits = m(x)
+    loss = ref_metrics.combined_loss(logits, y)
+    loss.backward()
+    d = {"x": npy(x), "y": npy(y), "logits": npy(logits), "loss": npy(loss)}
+    for k, v in sd0.items():
+        d["sd0/" + k] = npy(v)
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            d["sd1/" + k] = npy(v)
+    for k, p in m.named_parameters():
+        d["grad/" + k] = npy(p.grad)
+    m.eval()
+    with torch.no_grad():
+        d["logits_eval"] = npy(m(x))
+    np.savez_compressed(os.path.join(out, "small_unet.npz"), **d)
+
+
+def gen_doubleconv(ref_unet, out):
+    torch.manual_seed(11)
+    m = ref_unet.DoubleConv(3, 5, dropout_rate=0.0)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.3 * torch.randn(p.shape, generator=g))
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 3, 6, 5, 7, generator=g, requires_grad=True)
+    go = torch.randn(2, 5, 6, 5, 7, generator=g)
+    m.train()
+    o = m(x)
+    o.backward(go)
+    d = {"x": npy(x), "go": npy(go), "out": npy(o), "gx": npy(x.grad)}
+    for k, v in sd0.items():
+        d["sd0/" + k] = npy(v)
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            d["sd1/" + k] = npy(v)
+    for k, p in m.named_parameters():
+        d["grad/" + k] = npy(p.grad)
+    np.savez_compressed(os.path.join(out, "doubleconv.npz"), **d)
+
+
+def gen_losses(ref_metrics, ref_train_unet, out):
+    g = torch.Generator().manual_seed(21)
+    cases = {}
+    logits = 2.0 * torch.randn(2, 4, 8, 8, 8, generator=g)
+    labels = torch.randint(0, 4, (2, 1, 8, 8, 8), generator=g)
+    cases["uniform"] = (logits, labels)
+    lab2 = labels.clone()
+    lab2[lab2 == 2] = 0  # class 2 absent
+    cases["absent2"] = (1.5 * torch.randn(2, 4, 8, 8, 8, generator=g), lab2)
+    cases["single0"] = (torch.randn(1, 4, 4, 6, 8, generator=g), torch.zeros(1, 1, 4, 6, 8, dtype=torch.long))
+    onehot_lab = torch.randint(0, 4, (1, 1, 4, 4, 4), generator=g)
+    onehot = torch.full((1, 4, 4, 4, 4), -20.0)
+    onehot.scatter_(1, onehot_lab, 20.0)
+    cases["onehot"] = (onehot, onehot_lab)
+    cases["c3_noncubic"] = (torch.randn(2, 3, 3, 5, 7, generator=g), torch.randint(0, 3, (2, 1, 3, 5, 7), generator=g))
+
+    fns = {
+        "combined": ref_metrics.combined_loss,
+        "tversky55": lambda p, t: ref_metrics.tversky_loss(p, t, alpha=0.5, beta=0.5),
+        "ce_tversky73": ref_metrics.combined_ce_tversky_loss,
+        "ce_tversky55": ref_train_unet.get_loss_fn("ce_tversky"),
+        "dice": ref_train_unet.get_loss_fn("dice"),
+        "tversky_fn": ref_train_unet.get_loss_fn("tversky"),
+        "default_fn": ref_train_unet.get_loss_fn("whatever"),
+    }
+    d = {}
+    for cname, (lg, lb) in cases.items():
+        d[f"{cname}/logits"] = npy(lg)
+        d[f"{cname}/labels"] = npy(lb)
+        for fname, fn in fns.items():
+            z = lg.clone().requires_grad_(True)
+            l = fn(z, lb)
+            l.backward()
+            d[f"{cname}/{fname}/loss"] = npy(l)
+            d[f"{cname}/{fname}/grad"] = npy(z.grad)
+        # fp64 version of the default loss (tight reference for the closed-form gradient)
+        z = lg.double().clone().requires_grad_(True)
+        l = ref_metrics.combined_loss(z, lb)
+        l.backward()
+        d[f"{cname}/combined64/loss"] = npy(l)
+        d[f"{cname}/combined64/grad"] = npy(z.grad)
+        # distillation
+        t_logits = lg + 0.7 * torch.randn(lg.shape, generator=g)
+        d[f"{cname}/teacher"] = npy(t_logits)
+        for alpha, temp in ((0.7, 2.0), (0.3, 4.0)):
+            z = lg.clone().requires_grad_(True)
+            l = ref_metrics.distillation_loss(z, t_logits, lb, alpha, temp)
+            l.backward()
+            d[f"{cname}/distill_a{alpha}_t{temp}/loss"] = npy(l)
+            d[f"{cname}/distill_a{alpha}_t{temp}/grad"] = npy(z.grad)
+        # metrics (Q1: loop bound is the first spatial dim)
+        for mname in ("calculate_iou", "calculate_dice", "calculate_accuracy"):
+            v = getattr(ref_metrics, mname)(lg, lb)
+            d[f"{cname}/{mname}"] = np.asarray(float(v), dtype=np.float64)
+    # Q1 edge: D=2 < C=4 → only class 1 is scored
+    lg = torch.randn(2, 4, 2, 8, 8, generator=g)
+    lb = torch.randint(0, 4, (2, 1, 2, 8, 8), generator=g)
+    d["q1_d2/logits"], d["q1_d2/labels"] = npy(lg), npy(lb)
+    for mname in ("calculate_iou", "calculate_dice", "calculate_accuracy"):
+        d[f"q1_d2/{mname}"] = np.asarray(float(getattr(ref_metrics, mname)(lg, lb)), dtype=np.float64)
+    # no foreground class present at all → python 0 / 0.0
+    lb0 = torch.zeros(1, 1, 4, 4, 4, dtype=torch.long)
+    lg0 = torch.randn(1, 4, 4, 4, 4, generator=g)
+    d["nofg/logits"], d["nofg/labels"] = npy(lg0), npy(lb0)
+    for mname in ("calculate_iou", "calculate_dice", "calculate_accuracy"):
+        d[f"nofg/{mname}"] = np.asarray(float(getattr(ref_metrics, mname)(lg0, lb0)), dtype=np.float64)
+    np.savez_compressed(os.path.join(out, "losses_metrics.npz"), **d)
+
+
+SLICE_KEYS = [
+    "encoder.0.double_conv.0.weight", "encoder.0.double_conv.4.weight", "encoder.1.double_conv.0.weight",
+    "bottleneck.double_conv.4.bias", "upconvs.0.bias", "upconvs.3.weight", "decoder.3.double_conv.0.weight",
+    "decoder.3.double_conv.5.weight", "decoder.3.double_conv.5.bias", "final_conv.weight", "final_conv.bias",
+    "encoder.0.double_conv.1.weight", "encoder.2.double_conv.5.bias", "decoder.0.double_conv.1.weight",
+]
+
+
+def gen_default_unet(ref_unet, ref_metrics, out):
+    """Default architecture (5.65 M params): seeded init (digest stored), logits, loss, grads digest."""
+    d = {}
+    for tag, (n, s) in {"s16n2": (2, 16), "s32n1": (1, 32)}.items():
+        torch.manual_seed(0)
+        m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+        keys, dig = param_digest(m.state_dict())
+        d["param_keys"] = np.array(keys)
+        d["param_digest"] = dig
+        d["param_shapes"] = np.array([str(tuple(m.state_dict()[k].shape)) for k in keys])
+        d["param_dtypes"] = np.array([str(m.state_dict()[k].dtype) for k in keys])
+        x, y = synth(n, s, 1234)
+        m.train()
+        logits = m(x)
+        loss = ref_metrics.combined_loss(logits, y)
+        loss.backward()
+        d[f"{tag}/logits"] = npy(logits)
+        d[f"{tag}/loss"] = npy(loss)
+        d[f"{tag}/dice"] = npy(ref_metrics.calculate_dice(logits, y))
+        d[f"{tag}/iou"] = npy(ref_metrics.calculate_iou(logits, y))
+        d[f"{tag}/acc"] = npy(ref_metrics.calculate_accuracy(logits, y))
+        names = [k for k, _ in m.named_parameters()]
+        d["grad_names"] = np.array(names)
+        d[f"{tag}/grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()])
+        for k, p in m.named_parameters():
+            if k in SLICE_KEYS:
+                d[f"{tag}/grad/{k}"] = npy(p.grad)
+        bn = {k: v for k, v in m.state_dict().items() if "running" in k}
+        d[f"{tag}/bn_keys"] = np.array(sorted(bn.keys()))
+        d[f"{tag}/bn_after1"] = np.concatenate([npy(bn[k]).ravel() for k in sorted(bn.keys())])
+    # 5-step AdamW trajectory on a learnable (blocky) 16^3 N=2 problem; train_unet.py:378 defaults
+    torch.manual_seed(0)
+    m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+    x, y = synth(2, 16, 1234, blocky=True)
+    traj, dices = [], []
+    m.train()
+    for _ in range(5):
+        opt.zero_grad()
+        o = m(x)
+        l = ref_metrics.combined_loss(o, y)
+        l.backward()
+        opt.step()
+        traj.append(float(l))
+        dices.append(float(ref_metrics.calculate_dice(o, y)))
+    d["traj/loss"] = np.array(traj)
+    d["traj/dice"] = np.array(dices)
+    _, dig = param_digest(m.state_dict())
+    d["traj/param_digest_after5"] = dig
+    np.savez_compressed(os.path.join(out, "default_unet.npz"), **d)
+
+
+def gen_dann(ref_unet_dann, ref_metrics, ref_train_dann, out):
+    d = {}
+    # GRL
+    g = torch.Generator().manual_seed(31)
+    f = torch.randn(3, 5, generator=g, requires_grad=True)
+    r = ref_train_dann.grad_reverse(f, 0.2)
+    go = torch.randn(3, 5, generator=g)
+    r.backward(go)
+    d["grl/x"], d["grl/out"], d["grl/go"], d["grl/gx"] = npy(f), npy(r), npy(go), npy(f.grad)
+    # discriminator (eval → dropout off) forward/backward
+    torch.manual_seed(3)
+    disc = ref_train_dann.DomainDiscriminator(256)
+    dkeys, ddig = param_digest(disc.state_dict())
+    d["disc/param_keys"], d["disc/param_digest"] = np.array(dkeys), ddig
+    disc.eval()
+    feats = torch.randn(4, 256, generator=g, requires_grad=True)
+    lab = torch.tensor([0, 0, 1, 1])
+    pred = disc(feats)
+    l = torch.nn.CrossEntropyLoss()(pred, lab)
+    l.backward()
+    d["disc/feats"], d["disc/pred"], d["disc/loss"], d["disc/gfeats"] = npy(feats), npy(pred), npy(l), npy(feats.grad)
+    for k, p in disc.named_parameters():
+        d["disc/grad/" + k] = npy(p.grad)
+    # one full DANN step (train_dann.py:268-285), dropout disabled in both nets for determinism
+    torch.manual_seed(0)
+    seg = ref_unet_dann.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    torch.manual_seed(3)
+    disc = ref_train_dann.DomainDiscriminator(256)
+    for mod in disc.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    seg.train(); disc.train()
+    xs, ys = synth(2, 16, 1234)
+    xt, _ = synth(2, 16, 4321)
+    xs = xs.clamp(0, 1)                      # "CT-like"
+    xt = (xt - xt.min()) / (xt.max() - xt.min())  # "MRI-like"
+    lam = 0.2
+    so, sf = seg(xs, return_features=True)
+    task = ref_metrics.combined_loss(so, ys)
+    _, tf = seg(xt, return_features=True)
+    sp = disc(ref_train_dann.grad_reverse(sf, lam))
+    tp = disc(ref_train_dann.grad_reverse(tf, lam))
+    dl = torch.nn.CrossEntropyLoss()(torch.cat([sp, tp]), torch.tensor([0, 0, 1, 1]))
+    total = task + lam * dl
+    total.backward()
+    d["step/xs"], d["step/ys"], d["step/xt"] = npy(xs), npy(ys), npy(xt)
+    d["step/task"], d["step/domain"], d["step/total"] = npy(task), npy(dl), npy(total)
+    d["step/sfeat"], d["step/tfeat"] = npy(sf), npy(tf)
+    d["step/logits"] = npy(so)
+    d["step/seg_grad_names"] = np.array([k for k, _ in seg.named_parameters()])
+    d["step/seg_grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in seg.named_parameters()])
+    for k, p in seg.named_parameters():
+        if k in SLICE_KEYS:
+            d["step/seg_grad/" + k] = npy(p.grad)
+    for k, p in disc.named_parameters():
+        d["step/disc_grad/" + k] = npy(p.grad)
+    bn = {k: v for k, v in seg.state_dict().items() if "running" in k}
+    d["step/bn_after"] = np.concatenate([npy(bn[k]).ravel() for k in sorted(bn.keys())])
+    # unet_dann surface: return_features=False → (logits, None)
+    seg.eval()
+    with torch.no_grad():
+        o, none = seg(xs)
+    assert none is None
+    d["eval/logits"] = npy(o)
+    np.savez_compressed(os.path.join(out, "dann.npz"), **d)
+
+
+def gen_distill(ref_unet, ref_metrics, out):
+    """distill_unet.py:107-115 step: student(train) + teacher(eval,no_grad) + distillation_loss."""
+    d = {}
+    torch.manual_seed(0)
+    student = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    torch.manual_seed(1)
+    teacher = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    # give the teacher non-trivial running stats so eval-mode BN is exercised
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, b in teacher.named_buffers():
+            if k.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            if k.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    d["teacher_bn_keys"] = np.array(sorted(k for k, _ in teacher.named_buffers() if "running" in k))
+    d["teacher_bn"] = np.concatenate([npy(dict(teacher.named_buffers())[k]).ravel() for k in d["teacher_bn_keys"]])
+    student.train(); teacher.eval()
+    x, y = synth(2, 16, 1234)
+    s = student(x)
+    with torch.no_grad():
+        t = teacher(x)
+    l = ref_metrics.distillation_loss(s, t, y, 0.7, 2.0)
+    l.backward()
+    d["teacher_logits"], d["student_logits"], d["loss"] = npy(t), npy(s), npy(l)
+    d["grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in student.named_parameters()])
+    np.savez_compressed(os.path.join(out, "distill.npz"), **d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(8)
+    torch.use_deterministic_algorithms(False)
+    ref_unet, ref_unet_dann, ref_metrics, ref_train_unet, ref_train_dann = _import_reference()
+    gen_small_unet(ref_unet, ref_metrics, a.out)
+    gen_doubleconv(ref_unet, a.out)
+    gen_losses(ref_metrics, ref_train_unet, a.out)
+    gen_default_unet(ref_unet, ref_metrics, a.out)
+    gen_dann(ref_unet_dann, ref_metrics, ref_train_dann, a.out)
+    gen_distill(ref_unet, ref_metrics, a.out)
+    with open(os.path.join(a.out, "PROVENANCE.txt"), "w") as f:
+        f.write("generated by tools/gen_golden.py from /root/reference (fransiskusbudi/multimodal_segmentation_project @ 2025-08-24)\n")
+        f.write(f"torch {torch.__version__} CPU, numpy {np.__version__}, threads {torch.get_num_threads()}\n")
+    for fn in sorted(os.listdir(a.out)):
+        print(fn, os.path.getsize(os.path.join(a.out, fn)))
+
+
+if __name__ == "__main__":
+    main()
