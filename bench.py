@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json: 3D volumes/s, UNet3D 96^3 4-class training step
+(forward + Dice/CE loss + backward [+ gradient all-reduce] + AdamW + metrics) per node at N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  `value` = whole-job volumes/s (global batch * K / max-over-ranks time), inputs resident
+in HBM before timing.  `roofline` = the dominant kernel (measured live with HIP events on its own launches, same
+shapes as in the step) against the 8 TB/s HBM peak; `cpu_baseline` = the oracle's vanilla-torch restatement timed
+on the host cores (rank 0, N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_GB_PER_VOL_96_BF16 = 2.421   # SURVEY §8(d) / BASELINE.md §3: fwd+bwd compulsory traffic per 96^3 volume, bf16
+ALGO_GB_PER_VOL_96_F32 = 4.708
+
+
+def synth(n, s, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 1, s, s, s, generator=g)
+    y = torch.randint(0, 4, (n, 1, s, s, s), generator=g)
+    return x, y
+
+
+def cpu_baseline(size, batch, max_seconds=30.0):
+    """The oracle (oracle/torch_ref.py: vanilla torch.nn.functional restatement, fp32) on the host cores."""
+    from oracle import torch_ref
+    import multimodal_segmentation_project_amd as mi
+    torch.manual_seed(0)
+    m = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)     # CPU construction only (parameter shells)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    x, y = synth(batch, size, 1234)
+    cores = torch.get_num_threads()
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        logits, _, _ = torch_ref.unet3d_forward(sd, x, train=True)
+        loss = torch_ref.seg_loss(logits, y, "combined")
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_all > max_seconds and times:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {"value": batch / med, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} fwd+loss+bwd steps of UNet3D {size}^3 N={batch} fp32 after 1 warm-up (median)"}
+
+
+def roofline_dominant(size, batch, dtype_code, iters=10):
+    """Dominant kernel = the 3x3x3 conv of decoder.3.conv0 (32->16 @ full resolution): forward launch measured with
+    HIP events on the stream it runs on.  Algorithmic bytes = read x once + write y once (+ weights)."""
+    import ctypes as C
+    from multimodal_segmentation_project_amd import _lib
+    from multimodal_segmentation_project_amd._lib import call, ptr, stream_ptr
+    dev = "cuda"
+    cin, cout = 32, 16
+    esz = 2 if dtype_code == 1 else 4
+    T = torch.bfloat16 if dtype_code == 1 else torch.float32
+    n, d = batch, size
+    x = torch.randn((n, d, d, d, cin), device=dev).to(T)
+    w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
+    b = torch.zeros(cout, device=dev)
+    y = torch.empty((n, d, d, d, cout), device=dev, dtype=T)
+    wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, d, d)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    s = stream_ptr()
+    for _ in range(2):
+        call("mi3d_conv3_forward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(b), ptr(y), cout, cout, n, d, d, d,
+             ptr(ws), wsb, s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call("mi3d_conv3_forward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(b), ptr(y), cout, cout, n, d, d, d,
+             ptr(ws), wsb, s)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    vox = n * d ** 3
+    algo_bytes = vox * (cin + cout) * esz + cout * cin * 27 * 4
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "conv3 fwd 32->16 (decoder.3.conv0)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms,
+            "algorithmic_bytes_per_launch": algo_bytes}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (BASELINE config 2: 2)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.0, help="run_training.sh:31 ships --dropout_rate 0.0")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import multimodal_segmentation_project_amd as mi
+    from multimodal_segmentation_project_amd.trainer import TrainStep
+
+    torch.manual_seed(0)
+    model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=a.dropout).to(dev).train()
+    cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt,
+                   use_graph=(world == 1 and not a.no_graph))
+    x, y = synth(a.batch, a.size, 1234 + rank)
+    ts.load_batch(x.to(dev), y.to(dev))
+
+    for _ in range(a.warmup):
+        ts.step_static()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = ts.step_static()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    met = out.detach().cpu().tolist()
+
+    if rank == 0:
+        global_batch = a.batch * world
+        ms = dt / a.steps * 1e3
+        value = global_batch * a.steps / dt
+        scale = (a.size / 96.0) ** 3
+        algo_gb_step = (ALGO_GB_PER_VOL_96_BF16 if a.dtype == "bf16" else ALGO_GB_PER_VOL_96_F32) * scale * a.batch
+        res = {
+            "metric": "3D volumes/sec (96^3, 4-class) fwd+bwd per node", "value": value, "unit": "volumes/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"UNet3D(1->4, features 16/32/64/128) {a.size}^3 patch, per-GPU batch {a.batch}, "
+                                   f"fwd + Dice/CE loss + bwd + AdamW + metrics, dropout {a.dropout}",
+                       "global_batch": global_batch, "parallelism": f"dp{world}", "hipgraph": bool(ts.use_graph)},
+            "final_step": {"loss": met[0], "iou": met[1], "dice": met[2], "acc": met[3]},
+            "step_hbm_frac": algo_gb_step / (ms * 1e-3) / HBM_PEAK_GBS,
+            "step_algorithmic_gb": algo_gb_step,
+        }
+        if not a.no_roofline:
+            res["roofline"] = roofline_dominant(a.size, a.batch, 1 if a.dtype == "bf16" else 0)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.size, a.batch)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/*
+ * mi3d.h — C ABI of libmi3d.so: the MI355X-native (gfx950, hand-written HIP) 3D U-Net training hot path.
+ *
+ * The reference (fransiskusbudi/multimodal_segmentation_project) has NO FFI/plugin boundary: its hot path is
+ * reached through Python objects (models/unet.py UNet3D, models/unet_dann.py UNet3D, utils/metrics.py losses and
+ * metrics, train_dann.py GradientReversal/DomainDiscriminator) whose arithmetic is delegated to PyTorch.  This
+ * header is therefore the boundary a maintainer binds with ctypes underneath those objects (INTEGRATION.md shows
+ * the stub); every entry point names the reference interface (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - the library NEVER allocates, frees or synchronises: every buffer (inputs, outputs, saved activations,
+ *     scratch) is caller-owned device memory; sizes come from the *_workspace_bytes() queries.
+ *   - return 0 on success; < 0 argument/shape/dtype error; > 0 hipError_t.  mi3d_last_error() (thread-local)
+ *     describes the last failure.  No C++ exception crosses the boundary.
+ *   - callable from any host thread (PyTorch runs backward on its autograd thread); launches go to the stream
+ *     given; no thread-local device state is kept.
+ *   - external tensor layout = PyTorch's: NCDHW contiguous, float32 data, int64 labels.  Internally activations
+ *     are channels-last in `dtype` (MI3D_F32 exact path, MI3D_BF16 fast path with fp32 accumulation/statistics).
+ */
+#ifndef MI3D_H
+#define MI3D_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI3D_DTYPE_F32 0
+#define MI3D_DTYPE_BF16 1
+#define MI3D_MAX_LEVELS 6
+
+const char* mi3d_last_error(void);
+int mi3d_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Whole-network plan: UNet3D forward / backward.
+ * Replaces models/unet.py:64-90 (UNet3D.forward) and models/unet_dann.py:65-98 (forward with return_features),
+ * i.e. DoubleConv blocks (unet.py:6-22: Conv3d k3 p1 -> BatchNorm3d -> ReLU -> Dropout3d, twice), MaxPool3d(2,2)
+ * (:40,71), ConvTranspose3d(k2,s2) + cat(skip, x) (:56-58,79-84) and the final 1x1x1 conv (:62,87), plus their
+ * autograd backward (train_unet.py:225 accelerator.backward).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct mi3d_unet_desc {
+    int32_t in_channels, out_channels;      /* UNet3D(in_channels, out_channels, ...)  unet.py:34 */
+    int32_t n_levels;                       /* len(features), <= MI3D_MAX_LEVELS */
+    int32_t features[MI3D_MAX_LEVELS];      /* default [16,32,64,128] */
+    int32_t N, D, H, W;                     /* per-GPU batch and volume; D,H,W divisible by 2^n_levels */
+    int32_t dtype;                          /* internal activation dtype */
+    float bn_momentum, bn_eps;              /* 0.1, 1e-5 (nn.BatchNorm3d defaults) */
+} mi3d_unet_desc;
+
+/* Parameter / buffer pointer tables follow nn.Module.parameters() / .buffers() order of the reference model:
+ *   params : for each DoubleConv in [encoder.0..L-1, bottleneck] : conv0.w, conv0.b, bn0.w, bn0.b, conv1.w, conv1.b,
+ *            bn1.w, bn1.b ; then upconvs.0..L-1 : w, b ; then decoder.0..L-1 (8 each) ; then final_conv.w, .b
+ *   buffers: for each DoubleConv in [encoder..., bottleneck, decoder...] : bn0.running_mean, bn0.running_var,
+ *            bn0.num_batches_tracked(int64), bn1.(same three)
+ * grads uses the params order; entries may be NULL to skip a gradient. */
+int mi3d_unet_num_params(const mi3d_unet_desc* d);
+int mi3d_unet_num_buffers(const mi3d_unet_desc* d);
+size_t mi3d_unet_workspace_bytes(const mi3d_unet_desc* d);
+/* number of Dropout3d scale entries (sum over the 2*(2L+1) dropout layers of N*C); layout = block order
+ * [encoder..., bottleneck, decoder...], half 0 then half 1, each [N][C] */
+int64_t mi3d_unet_dropout_count(const mi3d_unet_desc* d);
+
+/* training != 0: batch statistics + running-stat update (BN train mode); == 0: running stats (eval mode).
+ * drop_scales: device float[mi3d_unet_dropout_count] holding 0 or 1/(1-p), or NULL (p = 0 / eval).
+ * logits: device float (N,out_channels,D,H,W).  gap_out: device float (N, 2*features[L-1]) or NULL
+ * (unet_dann.py:77-79).  The workspace keeps everything backward needs until the next forward. */
+int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
+                      const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Backward of the last mi3d_unet_forward on this workspace.  dlogits (N,out,D,H,W) float or NULL (target pass of
+ * DANN: only the GAP branch carries gradient, train_dann.py:271-285); dgap (N,2*features[L-1]) float or NULL, its
+ * contribution is scaled by gap_scale (gradient reversal folds in as gap_scale = -lambda, train_dann.py:29).
+ * accumulate != 0: grads += ; else grads = .
+ * Segments allow the caller to interleave gradient all-reduces: segment 0 = final_conv,
+ * 1..L = decoder.L-1..0 (+ its upconv), L+1 = bottleneck, L+2..2L+1 = encoder.L-1..0.  Run [seg_begin, seg_end). */
+int mi3d_unet_num_segments(const mi3d_unet_desc* d);
+int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
+                       const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale,
+                       int accumulate, int seg_begin, int seg_end, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* params-table index ranges whose gradients segment `seg` produces: ranges = {first0, last0, first1, last1}
+ * (half-open; the second range is the segment's upconv for decoder segments, otherwise {-1,-1}) */
+int mi3d_unet_segment_params(const mi3d_unet_desc* d, int seg, int* ranges);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Losses and metrics.  Replace utils/metrics.py:14-40 (combined_loss), :137-156 (tversky_loss), :158-167
+ * (combined_ce_tversky_loss), :169-190 (distillation_loss), train_unet.py:186-198 ('dice' variant) and
+ * utils/metrics.py:65-129 (calculate_iou / calculate_dice / calculate_accuracy, incl. its class-loop bound).
+ *   loss = w_ce*CE_mean + w_reg*mean_{c>=1} region_c + w_kd*T^2*mean_{n,c,v} KL(teacher||student)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct mi3d_loss_cfg {
+    float w_ce;
+    int32_t region_kind;        /* 0 none, 1 soft Dice (eps 1e-5), 2 Tversky(alpha,beta) (eps 1e-6) */
+    float w_reg, alpha, beta, eps;
+    float w_kd, temperature;    /* distillation: w_ce,w_reg pre-multiplied by alpha_kd; w_kd = 1-alpha_kd */
+} mi3d_loss_cfg;
+#define MI3D_LOSS_COEF_FLOATS 20
+size_t mi3d_seg_loss_workspace_bytes(int C);
+/* logits/teacher (N,C,V) float, labels (N,V) int64; loss_out: device float[1]; coef: device float[20] kept for bwd */
+int mi3d_seg_loss_forward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
+                          const mi3d_loss_cfg* cfg, float* loss_out, float* coef, void* workspace, void* stream);
+/* grad_out: device float[1] upstream gradient (NULL = 1) */
+int mi3d_seg_loss_backward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
+                           const mi3d_loss_cfg* cfg, const float* coef, const float* grad_out, float* dlogits,
+                           void* stream);
+size_t mi3d_seg_metrics_workspace_bytes(int C);
+/* out: device float[3] = {iou, dice, accuracy}; D = first spatial dim (reference loop bound, metrics.py:74,101) */
+int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,
+                     void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * DANN head.  Replaces train_dann.py:34-49 (DomainDiscriminator MLP 256-256-128-64-2, ReLU, Dropout 0.2) and
+ * :283 (nn.CrossEntropyLoss on the concatenated domain predictions).  GradientReversal (:22-32) is the
+ * gap_scale argument of mi3d_unet_backward plus gx_scale here.
+ * ---------------------------------------------------------------------------------------------------------- */
+int mi3d_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
+                        const float* drop, void* stream);
+/* y = the forward's output (ReLU mask); gx = gx_scale * dL/dx (gx_scale = -lambda folds the gradient reversal);
+ * workspace: M*Nout floats */
+int mi3d_linear_backward(const float* x, const float* w, const float* y, const float* gy, int M, int K, int Nout,
+                         int relu, const float* drop, float* gx, float* gw, float* gb, int accumulate,
+                         float gx_scale, float* workspace, void* stream);
+/* mean CE over M rows; dlogits = scale * d(loss)/d(logits) (may be NULL) */
+int mi3d_softmax_ce_rows(const float* logits, const int64_t* labels, int M, int C, float* loss, float* dlogits,
+                         float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer and RNG helpers on the step path.
+ * mi3d_adamw_step replaces torch.optim.AdamW(...).step() (train_unet.py:378,226) over one flat fp32 arena.
+ * step_dev: device int64 holding the number of steps taken so far (incremented by the call).
+ * ---------------------------------------------------------------------------------------------------------- */
+int mi3d_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float grad_scale, int64_t* step_dev, void* stream);
+/* Dropout3d (unet.py:14,18) channel masks: out[i] = 0 w.p. p else 1/(1-p); state_dev = device uint64[2]
+ * {seed, counter}, counter advanced by n.  Counter-based RNG: same distribution as torch, different stream. */
+int mi3d_dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Per-operator entry points (channels-last activations; used by the parity tests and by stand-alone modules).
+ * x/y: `dtype` tensors [N][D][H][W][C] with channel stride xcs/ycs (elements).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* nn.Conv3d(k=3,p=1) unet.py:11,15.  w (Cout,Cin,3,3,3) float.  workspace: mi3d_conv3_workspace_bytes */
+size_t mi3d_conv3_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W);
+int mi3d_conv3_forward(int in_dtype, int out_dtype, const void* x, int xcs, int Cin, const float* w, const float* bias,
+                       void* y, int ycs, int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* dx may be NULL (first layer); dW (Cout,Cin,3,3,3), db (Cout) float */
+int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int Cin, const float* w, const void* dy,
+                        int dycs, int Cout, void* dx, int dxcs, float* dW, float* db, int accumulate, int N, int D,
+                        int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+/* BatchNorm3d(train) + ReLU + Dropout3d fused; stat: device float[4*C] saved for backward */
+size_t mi3d_bn_workspace_bytes(int C);
+int mi3d_bn_relu_drop_forward(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float momentum, float eps, int training, const float* drop, void* z, int zcs, float* stat,
+                              void* workspace, void* stream);
+int mi3d_bn_relu_drop_backward(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
+                               const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
+                               int accumulate, void* workspace, void* stream);
+int mi3d_maxpool2_forward(int dtype, const void* z, int zcs, int C, int N, int D, int H, int W, void* p, int pcs,
+                          void* stream);
+int mi3d_maxpool2_backward(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs,
+                           void* dz, int dzcs, int C, int N, int D, int H, int W, void* stream);
+/* ConvTranspose3d(k2,s2) unet.py:56-58.  w (Cin,Cout,2,2,2) float; geometry = INPUT volume */
+size_t mi3d_upconv2_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W);
+int mi3d_upconv2_forward(int dtype, const void* x, int xcs, int Cin, const float* w, const float* bias, void* y, int ycs,
+                         int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int mi3d_upconv2_backward(int dtype, const void* x, int xcs, int Cin, const float* w, const void* gy, int gycs, int Cout,
+                          void* dx, int dxcs, float* dW, float* db, int accumulate, int N, int D, int H, int W,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* layout helpers: NCDHW float <-> channels-last `dtype` */
+int mi3d_ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int dcs, int C, int N, int64_t V, void* stream);
+int mi3d_ndhwc_to_ncdhw(int dtype, const void* src, int scs, float* dst, int C, int N, int64_t V, void* stream);
+
+/* hipGraph capture helpers (launch-bound step loops): capture everything launched on `stream` between begin/end */
+int mi3d_graph_begin(void* stream);
+int mi3d_graph_end(void* stream, void** graph_exec_out);
+int mi3d_graph_launch(void* graph_exec, void* stream);
+int mi3d_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI3D_H */

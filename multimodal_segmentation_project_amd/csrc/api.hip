@@ -1,0 +1,191 @@
+// api.hip — extern "C" wrappers (include/mi3d.h) around the per-operator launchers, losses, DANN head,
+// optimizer and hipGraph helpers.  The whole-network entry points live in plan.hip.
+#include "../../include/mi3d.h"
+#include "ops.h"
+
+static_assert(MI3D_LOSS_COEF_FLOATS >= 2 * MI3D_MAX_CLASSES + 4, "coef buffer too small");
+
+static inline LossCfg to_cfg(const mi3d_loss_cfg* c) {
+    LossCfg k;
+    k.w_ce = c->w_ce; k.region_kind = c->region_kind; k.w_reg = c->w_reg; k.alpha = c->alpha; k.beta = c->beta;
+    k.eps = c->eps; k.w_kd = c->w_kd; k.temp = c->temperature > 0.f ? c->temperature : 1.f;
+    return k;
+}
+
+extern "C" {
+
+size_t mi3d_seg_loss_workspace_bytes(int C) { return seg_loss_ws_bytes(C); }
+int mi3d_seg_loss_forward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
+                          const mi3d_loss_cfg* cfg, float* loss_out, float* coef, void* workspace, void* stream) {
+    MI3D_CHECK_ARG(logits && labels && cfg && loss_out && coef && workspace, "mi3d_seg_loss_forward: null pointer");
+    return seg_loss_fwd(logits, labels, teacher, N, C, V, to_cfg(cfg), loss_out, coef, workspace, (hipStream_t)stream);
+}
+int mi3d_seg_loss_backward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
+                           const mi3d_loss_cfg* cfg, const float* coef, const float* grad_out, float* dlogits,
+                           void* stream) {
+    MI3D_CHECK_ARG(logits && labels && cfg && coef && dlogits, "mi3d_seg_loss_backward: null pointer");
+    return seg_loss_bwd(logits, labels, teacher, N, C, V, to_cfg(cfg), coef, grad_out, dlogits, (hipStream_t)stream);
+}
+size_t mi3d_seg_metrics_workspace_bytes(int C) { return seg_metrics_ws_bytes(C); }
+int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,
+                     void* workspace, void* stream) {
+    MI3D_CHECK_ARG(logits && labels && out && workspace, "mi3d_seg_metrics: null pointer");
+    return seg_metrics(logits, labels, N, C, D, V, out, workspace, (hipStream_t)stream);
+}
+
+int mi3d_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
+                        const float* drop, void* stream) {
+    MI3D_CHECK_ARG(x && w && y && M > 0 && K > 0 && Nout > 0, "mi3d_linear_forward: bad arguments");
+    return linear_fwd(x, w, b, y, M, K, Nout, relu, drop, (hipStream_t)stream);
+}
+int mi3d_linear_backward(const float* x, const float* w, const float* y, const float* gy, int M, int K, int Nout,
+                         int relu, const float* drop, float* gx, float* gw, float* gb, int accumulate, float gx_scale,
+                         float* workspace, void* stream) {
+    MI3D_CHECK_ARG(x && w && y && gy && workspace, "mi3d_linear_backward: null pointer");
+    return linear_bwd(x, w, y, gy, M, K, Nout, relu, drop, gx, gw, gb, accumulate, gx_scale, workspace, (hipStream_t)stream);
+}
+int mi3d_softmax_ce_rows(const float* logits, const int64_t* labels, int M, int C, float* loss, float* dlogits,
+                         float scale, void* stream) {
+    MI3D_CHECK_ARG(logits && labels, "mi3d_softmax_ce_rows: null pointer");
+    return softmax_ce_rows(logits, labels, M, C, loss, dlogits, scale, (hipStream_t)stream);
+}
+
+int mi3d_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float grad_scale, int64_t* step_dev, void* stream) {
+    MI3D_CHECK_ARG(p && g && m && v && step_dev && n >= 0, "mi3d_adamw_step: bad arguments");
+    return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_dev, (hipStream_t)stream);
+}
+int mi3d_dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, void* stream) {
+    MI3D_CHECK_ARG(out && state_dev && n >= 0 && p >= 0.f && p <= 1.f, "mi3d_dropout_scales: bad arguments");
+    return dropout_scales(out, n, p, state_dev, (hipStream_t)stream);
+}
+
+// ---- per-operator entry points ------------------------------------------------------------------
+size_t mi3d_conv3_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W) {
+    Geo g{N, D, H, W};
+    return (conv3_direct_pack_floats(Cin, Cout) + conv3_direct_pack_floats(Cout, Cin) +
+            conv3_direct_wgrad_ws_floats(Cin, Cout, g)) * sizeof(float);
+}
+int mi3d_conv3_forward(int in_dtype, int out_dtype, const void* x, int xcs, int Cin, const float* w, const float* bias,
+                       void* y, int ycs, int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    MI3D_CHECK_ARG(x && w && y && workspace, "mi3d_conv3_forward: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= mi3d_conv3_workspace_bytes(Cin, Cout, N, D, H, W), "mi3d_conv3_forward: workspace too small");
+    float* wpf = (float*)workspace;
+    float* wpd = wpf + conv3_direct_pack_floats(Cin, Cout);
+    hipStream_t s = (hipStream_t)stream;
+    MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
+    return conv3_direct_fwd(in_dtype, out_dtype, x, xcs, Cin, wpf, bias, y, ycs, Cout, Geo{N, D, H, W}, s);
+}
+int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int Cin, const float* w, const void* dy,
+                        int dycs, int Cout, void* dx, int dxcs, float* dW, float* db, int accumulate, int N, int D, int H,
+                        int W, void* workspace, size_t workspace_bytes, void* stream) {
+    MI3D_CHECK_ARG(x && w && dy && workspace, "mi3d_conv3_backward: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= mi3d_conv3_workspace_bytes(Cin, Cout, N, D, H, W), "mi3d_conv3_backward: workspace too small");
+    Geo g{N, D, H, W};
+    float* wpf = (float*)workspace;
+    float* wpd = wpf + conv3_direct_pack_floats(Cin, Cout);
+    float* slabs = wpd + conv3_direct_pack_floats(Cout, Cin);
+    hipStream_t s = (hipStream_t)stream;
+    MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
+    if (dx) MI3D_TRY(conv3_direct_fwd(dy_dtype, dy_dtype, dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, s));
+    if (dW || db)
+        MI3D_TRY(conv3_direct_wgrad(x_dtype, dy_dtype, x, xcs, Cin, dy, dycs, Cout, g, dW, db, accumulate, slabs,
+                                    conv3_direct_wgrad_ws_floats(Cin, Cout, g), s));
+    return 0;
+}
+
+size_t mi3d_bn_workspace_bytes(int C) { return bn_ws_floats(C) * sizeof(float); }
+int mi3d_bn_relu_drop_forward(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                              float momentum, float eps, int training, const float* drop, void* z, int zcs, float* stat,
+                              void* workspace, void* stream) {
+    MI3D_CHECK_ARG(y && gamma && beta && z && stat && workspace, "mi3d_bn_relu_drop_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (training)
+        MI3D_TRY(bn_train_stats(dtype, y, ycs, C, M, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                                eps, stat, (float*)workspace, s));
+    else {
+        MI3D_CHECK_ARG(running_mean && running_var, "eval-mode BN needs running statistics");
+        MI3D_TRY(bn_eval_stats(C, gamma, beta, running_mean, running_var, eps, stat, s));
+    }
+    return bn_apply_relu_drop(dtype, y, ycs, C, M, V, stat, drop, z, zcs, s);
+}
+int mi3d_bn_relu_drop_backward(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
+                               const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
+                               int accumulate, void* workspace, void* stream) {
+    MI3D_CHECK_ARG(dz && y && stat && dy && workspace, "mi3d_bn_relu_drop_backward: null pointer");
+    return bn_bwd(dtype, dz, dzcs, y, ycs, C, M, V, stat, drop, dy, dycs, dgamma, dbeta, accumulate, (float*)workspace,
+                  (hipStream_t)stream);
+}
+int mi3d_maxpool2_forward(int dtype, const void* z, int zcs, int C, int N, int D, int H, int W, void* p, int pcs,
+                          void* stream) {
+    MI3D_CHECK_ARG(z && p, "mi3d_maxpool2_forward: null pointer");
+    return maxpool2_fwd(dtype, z, zcs, C, Geo{N, D, H, W}, p, pcs, (hipStream_t)stream);
+}
+int mi3d_maxpool2_backward(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs,
+                           void* dz, int dzcs, int C, int N, int D, int H, int W, void* stream) {
+    MI3D_CHECK_ARG(dp && z && dz, "mi3d_maxpool2_backward: null pointer");
+    return maxpool2_bwd(dtype, dp, dpcs, z, zcs, dskip, dskipcs, dz, dzcs, C, Geo{N, D, H, W}, (hipStream_t)stream);
+}
+size_t mi3d_upconv2_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W) {
+    return (upconv2_pack_floats(Cin, Cout) + upconv2_bwd_ws_floats(Cin, Cout, Geo{N, D, H, W})) * sizeof(float);
+}
+int mi3d_upconv2_forward(int dtype, const void* x, int xcs, int Cin, const float* w, const float* bias, void* y, int ycs,
+                         int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    MI3D_CHECK_ARG(x && w && y && workspace, "mi3d_upconv2_forward: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= mi3d_upconv2_workspace_bytes(Cin, Cout, N, D, H, W), "mi3d_upconv2_forward: workspace too small");
+    float* wf = (float*)workspace;
+    float* wb = wf + (size_t)cdiv(Cout, 8) * Cin * 64;
+    MI3D_TRY(upconv2_pack(w, Cin, Cout, wf, wb, (hipStream_t)stream));
+    return upconv2_fwd(dtype, x, xcs, Cin, wf, bias, y, ycs, Cout, Geo{N, D, H, W}, (hipStream_t)stream);
+}
+int mi3d_upconv2_backward(int dtype, const void* x, int xcs, int Cin, const float* w, const void* gy, int gycs, int Cout,
+                          void* dx, int dxcs, float* dW, float* db, int accumulate, int N, int D, int H, int W,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    MI3D_CHECK_ARG(x && w && gy && workspace, "mi3d_upconv2_backward: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= mi3d_upconv2_workspace_bytes(Cin, Cout, N, D, H, W), "mi3d_upconv2_backward: workspace too small");
+    Geo g{N, D, H, W};
+    float* wf = (float*)workspace;
+    float* wb = wf + (size_t)cdiv(Cout, 8) * Cin * 64;
+    float* slabs = (float*)workspace + upconv2_pack_floats(Cin, Cout);
+    MI3D_TRY(upconv2_pack(w, Cin, Cout, wf, wb, (hipStream_t)stream));
+    return upconv2_bwd(dtype, x, xcs, Cin, gy, gycs, Cout, wb, dx, dxcs, dW, db, accumulate, slabs,
+                       upconv2_bwd_ws_floats(Cin, Cout, g), g, (hipStream_t)stream);
+}
+int mi3d_ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int dcs, int C, int N, int64_t V, void* stream) {
+    MI3D_CHECK_ARG(src && dst, "mi3d_ncdhw_to_ndhwc: null pointer");
+    return ncdhw_to_ndhwc(dtype, src, dst, dcs, C, N, V, (hipStream_t)stream);
+}
+int mi3d_ndhwc_to_ncdhw(int dtype, const void* src, int scs, float* dst, int C, int N, int64_t V, void* stream) {
+    MI3D_CHECK_ARG(src && dst, "mi3d_ndhwc_to_ncdhw: null pointer");
+    return ndhwc_to_ncdhw(dtype, src, scs, dst, C, N, V, (hipStream_t)stream);
+}
+
+// ---- hipGraph helpers ---------------------------------------------------------------------------
+int mi3d_graph_begin(void* stream) {
+    MI3D_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+int mi3d_graph_end(void* stream, void** graph_exec_out) {
+    MI3D_CHECK_ARG(graph_exec_out, "mi3d_graph_end: null output");
+    hipGraph_t graph = nullptr;
+    MI3D_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    MI3D_HIP(e);
+    *graph_exec_out = (void*)exec;
+    return 0;
+}
+int mi3d_graph_launch(void* graph_exec, void* stream) {
+    MI3D_CHECK_ARG(graph_exec, "mi3d_graph_launch: null graph");
+    MI3D_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return 0;
+}
+int mi3d_graph_destroy(void* graph_exec) {
+    if (graph_exec) MI3D_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+// bn.hip — BatchNorm3d (train/eval) fused with ReLU and Dropout3d, forward and backward.
+// Reference semantics: nn.BatchNorm3d(C) -> nn.ReLU(inplace) -> nn.Dropout3d(p), models/unet.py:12-14,16-18.
+//
+// All kernels are HBM-bound streaming passes over a channels-last [M][C] activation (M = N*D*H*W):
+//   stats   : R y                      -> per-block (sum, sumsq) partials -> finalize (double, fixed order)
+//   apply   : R y, W z                 z = drop[n,c] * relu(a*y + b)
+//   bwd red.: R dz, R y                -> (sum dyh, sum dyh*xhat) partials -> finalize
+//   bwd app.: R dz, R y, W dy          dy = g*(dyh - c1 - xhat*c2)
+// Per-channel reductions: lane-private fp32 accumulation -> LDS across the rows of a block -> one partial
+// per block -> a finalize kernel that sums the partials in double in a fixed order (bitwise reproducible,
+// no float atomics).
+#include "ops.h"
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int MAXBLK = 1024;
+
+struct RowMap {
+    int G;   // channel groups per row (C / VEC)
+    int R;   // rows handled per block iteration (BLK / G)
+};
+
+template <int VEC> __device__ __forceinline__ bool row_map(int C, int& r, int& g, int& R) {
+    int G = C / VEC;
+    R = BLK / G;
+    r = threadIdx.x / G;
+    g = threadIdx.x - r * G;
+    return r < R;
+}
+
+// reduce K lane-private quantities per channel over the block; result to part[blockIdx.x][k][c]
+template <int VEC, int K> __device__ __forceinline__ void block_colreduce(const float (&acc)[K][VEC], int C, bool active,
+                                                                           float* lds, float* part) {
+    int G = C / VEC, R = BLK / G;
+    int r = threadIdx.x / G, g = threadIdx.x - r * G;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int i = 0; i < VEC; i++) lds[((k * R + r) * C) + g * VEC + i] = acc[k][i];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < K * C; idx += BLK) {
+        int k = idx / C, c = idx - k * C;
+        float s = 0.f;
+        for (int rr = 0; rr < R; rr++) s += lds[(k * R + rr) * C + c];
+        part[((size_t)blockIdx.x * K + k) * C + c] = s;
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void bn_stats_kernel(const T* __restrict__ y, int ycs, int C, int64_t M,
+                                                       float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int r, g, R;
+    bool active = row_map<VEC>(C, r, g, R);
+    float acc[2][VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) acc[0][i] = acc[1][i] = 0.f;
+    if (active) {
+        for (int64_t row = (int64_t)blockIdx.x * R + r; row < M; row += (int64_t)gridDim.x * R) {
+            float v[VEC];
+            ldv<T, VEC>(y + row * ycs + g * VEC, v);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) { acc[0][i] += v[i]; acc[1][i] += v[i] * v[i]; }
+        }
+    }
+    block_colreduce<VEC, 2>(acc, C, active, lds, part);
+}
+
+// one 64-lane block per channel: double sums of the partials in a fixed order
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
+                                         const float* gamma, const float* beta, float* running_mean,
+                                         float* running_var, int64_t* nbt, float momentum, float eps,
+                                         float* stat) {
+    int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        s += (double)part[((size_t)b * 2 + 0) * C + c];
+        q += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) {
+        double mean = s / (double)M;
+        double var = q / (double)M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double inv = 1.0 / sqrt(var + (double)eps);
+        float a = (float)((double)gamma[c] * inv);
+        stat[c] = (float)mean;
+        stat[C + c] = (float)inv;
+        stat[2 * C + c] = a;
+        stat[3 * C + c] = (float)((double)beta[c] - mean * (double)gamma[c] * inv);
+        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        if (running_var) {
+            double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                     const float* rv, float eps, float* stat) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double inv = 1.0 / sqrt((double)rv[c] + (double)eps);
+    stat[c] = rm[c];
+    stat[C + c] = (float)inv;
+    stat[2 * C + c] = (float)((double)gamma[c] * inv);
+    stat[3 * C + c] = (float)((double)beta[c] - (double)rm[c] * (double)gamma[c] * inv);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, int ycs, int C, int64_t M, int64_t V,
+                                                       const float* __restrict__ stat, const float* __restrict__ drop,
+                                                       T* __restrict__ z, int zcs) {
+    int G = C / VEC;
+    int64_t total = M * G;
+    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+        int64_t row = idx / G;
+        int g = (int)(idx - row * G);
+        float v[VEC], o[VEC];
+        ldv<T, VEC>(y + row * ycs + g * VEC, v);
+        const float* a = stat + 2 * C + g * VEC;
+        const float* b = stat + 3 * C + g * VEC;
+        const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            float t = fmaf(v[i], a[i], b[i]);
+            t = t > 0.f ? t : 0.f;
+            o[i] = dr ? t * dr[i] : t;
+        }
+        stv<T, VEC>(z + row * zcs + g * VEC, o);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
+                                                            int ycs, int C, int64_t M, int64_t V,
+                                                            const float* __restrict__ stat,
+                                                            const float* __restrict__ drop, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int r, g, R;
+    bool active = row_map<VEC>(C, r, g, R);
+    float acc[2][VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) acc[0][i] = acc[1][i] = 0.f;
+    if (active) {
+        float mean[VEC], inv[VEC], a[VEC], b[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            mean[i] = stat[g * VEC + i]; inv[i] = stat[C + g * VEC + i];
+            a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i];
+        }
+        for (int64_t row = (int64_t)blockIdx.x * R + r; row < M; row += (int64_t)gridDim.x * R) {
+            float yv[VEC], gv[VEC];
+            ldv<T, VEC>(y + row * ycs + g * VEC, yv);
+            ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
+            const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                float pre = fmaf(yv[i], a[i], b[i]);
+                float m = pre > 0.f ? (dr ? dr[i] : 1.f) : 0.f;
+                float dyh = gv[i] * m;
+                acc[0][i] += dyh;
+                acc[1][i] += dyh * (yv[i] - mean[i]) * inv[i];
+            }
+        }
+    }
+    block_colreduce<VEC, 2>(acc, C, active, lds, part);
+}
+
+// coef[3][C] = {c1 = sum_dyh / M, c2 = sum_dyh_xhat / M, g = gamma*invstd(=a)}; dgamma, dbeta (+)=
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
+                                       const float* stat, float* dgamma, float* dbeta, int accumulate, float* coef) {
+    int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < nblk; b += 64) {
+        s += (double)part[((size_t)b * 2 + 0) * C + c];
+        q += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (lane == 0) {
+        coef[c] = (float)(s / (double)M);
+        coef[C + c] = (float)(q / (double)M);
+        coef[2 * C + c] = stat[2 * C + c];
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void bn_bwd_apply_kernel(const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
+                                                           int ycs, int C, int64_t M, int64_t V,
+                                                           const float* __restrict__ stat, const float* __restrict__ coef,
+                                                           const float* __restrict__ drop, T* __restrict__ dy, int dycs) {
+    int G = C / VEC;
+    int64_t total = M * G;
+    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+        int64_t row = idx / G;
+        int g = (int)(idx - row * G);
+        float yv[VEC], gv[VEC], o[VEC];
+        ldv<T, VEC>(y + row * ycs + g * VEC, yv);
+        ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
+        const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
+        int c0 = g * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            float a = stat[2 * C + c0 + i], b = stat[3 * C + c0 + i];
+            float pre = fmaf(yv[i], a, b);
+            float m = pre > 0.f ? (dr ? dr[i] : 1.f) : 0.f;
+            float dyh = gv[i] * m;
+            float xh = (yv[i] - stat[c0 + i]) * stat[C + c0 + i];
+            o[i] = coef[2 * C + c0 + i] * (dyh - coef[c0 + i] - xh * coef[C + c0 + i]);
+        }
+        stv<T, VEC>(dy + row * dycs + g * VEC, o);
+    }
+}
+
+inline bool vec8_ok(int C, int cs_a, int cs_b, const void* pa, const void* pb, int esz) {
+    return C % 8 == 0 && cs_a % 8 == 0 && cs_b % 8 == 0 && ((uintptr_t)pa % 16 == 0) && ((uintptr_t)pb % 16 == 0) &&
+           (C / 8) <= BLK && esz > 0;
+}
+
+inline int reduce_grid(int64_t M, int R) {
+    int64_t want = (M + (int64_t)R * 4 - 1) / ((int64_t)R * 4);
+    if (want < 1) want = 1;
+    return (int)(want > MAXBLK ? MAXBLK : want);
+}
+inline int stream_grid(int64_t total) {
+    int64_t want = (total + BLK - 1) / BLK;
+    if (want < 1) want = 1;
+    return (int)(want > 256 * 8 ? 256 * 8 : want);
+}
+
+}  // namespace
+
+size_t bn_ws_floats(int C) { return (size_t)MAXBLK * 2 * C + 3 * (size_t)C; }
+
+int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* stat,
+                   float* ws, hipStream_t s) {
+    MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_train_stats: bad C=%d M=%lld", C, (long long)M);
+    DISPATCH_T(dtype, T, {
+        bool v8 = vec8_ok(C, ycs, ycs, y, y, sizeof(T));
+        int G = v8 ? C / 8 : C, R = BLK / G;
+        int nblk = reduce_grid(M, R);
+        size_t lds = (size_t)2 * R * C * sizeof(float);
+        if (v8) bn_stats_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)y, ycs, C, M, ws);
+        else bn_stats_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)y, ycs, C, M, ws);
+        MI3D_LAUNCH_CHECK();
+        bn_stats_finalize_kernel<<<C, 64, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt,
+                                                 momentum, eps, stat);
+        MI3D_LAUNCH_CHECK();
+    });
+    return 0;
+}
+
+int bn_eval_stats(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                  float* stat, hipStream_t s) {
+    bn_eval_stats_kernel<<<cdiv(C, 64), 64, 0, s>>>(C, gamma, beta, rm, rv, eps, stat);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* stat,
+                       const float* drop, void* z, int zcs, hipStream_t s) {
+    MI3D_CHECK_ARG(C >= 1 && M >= 1, "bn_apply: bad shape");
+    DISPATCH_T(dtype, T, {
+        if (vec8_ok(C, ycs, zcs, y, z, sizeof(T)))
+            bn_apply_kernel<T, 8><<<stream_grid(M * (C / 8)), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
+        else
+            bn_apply_kernel<T, 1><<<stream_grid(M * C), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
+        MI3D_LAUNCH_CHECK();
+    });
+    return 0;
+}
+
+int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
+           const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta, int accumulate,
+           float* ws, hipStream_t s) {
+    MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_bwd: bad C=%d", C);
+    float* part = ws;
+    float* coef = ws + (size_t)MAXBLK * 2 * C;
+    DISPATCH_T(dtype, T, {
+        bool v8 = vec8_ok(C, ycs, dzcs, y, dz, sizeof(T)) && dycs % 8 == 0 && ((uintptr_t)dy % 16 == 0);
+        int G = v8 ? C / 8 : C, R = BLK / G;
+        int nblk = reduce_grid(M, R);
+        size_t lds = (size_t)2 * R * C * sizeof(float);
+        if (v8) bn_bwd_reduce_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
+        else bn_bwd_reduce_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
+        MI3D_LAUNCH_CHECK();
+        bn_bwd_finalize_kernel<<<C, 64, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);
+        MI3D_LAUNCH_CHECK();
+        if (v8)
+            bn_bwd_apply_kernel<T, 8><<<stream_grid(M * (C / 8)), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
+        else
+            bn_bwd_apply_kernel<T, 1><<<stream_grid(M * C), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
+        MI3D_LAUNCH_CHECK();
+    });
+    return 0;
+}

@@ -1,0 +1,119 @@
+// common.h — shared device/host helpers for the mi3d HIP library (gfx950 / CDNA4 only).
+//
+// Internal activation layout: channels-last  [N][D][H][W][C]  ("NDHWC"), element type T in
+// {float, bf16}, with an explicit channel stride `cs` (elements) so that a tensor can be a
+// channel slice of a wider buffer (the skip-concat buffers: encoder output = channels [0,C),
+// upconv output = channels [C,2C) of one [.., 2C] buffer; models/unet.py:84 becomes free).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+enum { MI3D_F32 = 0, MI3D_BF16 = 1 };
+
+// ---- error plumbing (no C++ exception ever crosses the C ABI) ---------------------------------
+void mi3d_set_error(const char* fmt, ...);
+#define MI3D_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            mi3d_set_error(__VA_ARGS__);          \
+            return -1;                            \
+        }                                         \
+    } while (0)
+#define MI3D_HIP(call)                                                                   \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            mi3d_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                              \
+        }                                                                                \
+    } while (0)
+#define MI3D_LAUNCH_CHECK() MI3D_HIP(hipGetLastError())
+#define MI3D_TRY(expr)          \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+#ifdef __HIPCC__
+#define MI3D_HD __host__ __device__
+#else
+#define MI3D_HD
+#endif
+MI3D_HD static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// round-trip through the storage type (what a consumer of the stored value will see)
+template <typename T> __device__ __forceinline__ float round_to(float v) { return to_f<T>(from_f<T>(v)); }
+
+// 8-wide vector load/store of T as floats (16 B for bf16, 2 x 16 B for f32).  p must be 16-B aligned.
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+template <> __device__ __forceinline__ void ld8<bf16>(const bf16* p, float (&o)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = (float)a[i];
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = (bf16)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+// VEC-generic (VEC = 8 vector path, VEC = 1 scalar path for odd channel counts)
+template <typename T, int VEC> __device__ __forceinline__ void ldv(const T* p, float (&o)[VEC]) {
+    if constexpr (VEC == 8) ld8<T>(p, o);
+    else {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) o[i] = to_f<T>(p[i]);
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void stv(T* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 8) st8<T>(p, v);
+    else {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) p[i] = from_f<T>(v[i]);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif  // __HIPCC__
+
+// dtype dispatch for launchers: DISPATCH_T(dtype, T, { ... uses T ... })
+#define DISPATCH_T(dtype, T, ...)                                  \
+    do {                                                           \
+        if ((dtype) == MI3D_F32) { typedef float T; __VA_ARGS__ }  \
+        else { typedef bf16 T; __VA_ARGS__ }                       \
+    } while (0)

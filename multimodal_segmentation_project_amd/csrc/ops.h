@@ -1,0 +1,113 @@
+// ops.h — internal launcher API (C++), one function per kernel family.  Every launcher
+//   * takes raw device pointers + explicit channel strides (see common.h for the layout),
+//   * launches on the stream it is given and never synchronises, allocates or frees,
+//   * returns 0, a negative argument error, or a positive hipError_t.
+// The extern "C" boundary (include/mi3d.h, api.hip) and the whole-network plan (plan.hip) sit on top.
+#pragma once
+#include "common.h"
+
+struct Geo {
+    int N, D, H, W;
+    int64_t V() const { return (int64_t)D * H * W; }
+    int64_t M() const { return (int64_t)N * D * H * W; }
+};
+
+// ---- 3x3x3 convolution, direct (any channel count, any dtype; fp32 FMA) -------------- conv3_direct.hip
+// Reference: nn.Conv3d(k=3,p=1) models/unet.py:11,15.  Weights arrive in torch layout (Cout,Cin,3,3,3) fp32.
+size_t conv3_direct_pack_floats(int Cin, int Cout);          // size of ONE packed operand (fwd or dgrad)
+int conv3_direct_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad, hipStream_t s);
+// y[v,co] = bias[co] + sum_{tap,ci} x[v+tap,ci] * wp ;  dgrad = same call with wp_dgrad, (Cin,Cout) swapped, bias NULL
+int conv3_direct_fwd(int in_dtype, int out_dtype, const void* x, int xcs, int Cin, const float* wp,
+                     const float* bias, void* y, int ycs, int Cout, Geo g, hipStream_t s);
+// dW[co,ci,tap] (+)= sum_v dy[v,co] x[v+tap,ci] ; db[co] (+)= sum_v dy[v,co].  Deterministic slab reduction.
+size_t conv3_direct_wgrad_ws_floats(int Cin, int Cout, Geo g);
+int conv3_direct_wgrad(int x_dtype, int dy_dtype, const void* x, int xcs, int Cin, const void* dy, int dycs,
+                       int Cout, Geo g, float* dW, float* db, int accumulate, float* ws, size_t ws_floats,
+                       hipStream_t s);
+
+// ---- BatchNorm3d + ReLU + Dropout3d ---------------------------------------------------------- bn.hip
+// Reference: nn.BatchNorm3d / nn.ReLU(inplace) / nn.Dropout3d  models/unet.py:12-14,16-18.
+// stat buffer layout: float[4][C] = {mean, invstd, a = gamma*invstd, b = beta - mean*a}
+size_t bn_ws_floats(int C);
+int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                   float eps, float* stat, float* ws, hipStream_t s);
+int bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean,
+                  const float* running_var, float eps, float* stat, hipStream_t s);
+// z = drop[n,c] * relu(a*y + b)      (drop == NULL -> 1)
+int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* stat,
+                       const float* drop, void* z, int zcs, hipStream_t s);
+// dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)), dyh = dz*drop*[a*y+b > 0]; dgamma, dbeta (+)=
+int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
+           const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
+           int accumulate, float* ws, hipStream_t s);
+
+// ---- MaxPool3d(2,2) ------------------------------------------------------------------------ pool.hip
+// Reference: models/unet.py:40,71.  g = INPUT geometry (even D,H,W required).
+int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int pcs, hipStream_t s);
+// dz = dskip (or 0) + route(dp) to the first max in (d,h,w) scan order
+int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs,
+                 void* dz, int dzcs, int C, Geo g, hipStream_t s);
+
+// ---- ConvTranspose3d(k=2,s=2) ------------------------------------------------------------ upconv.hip
+// Reference: models/unet.py:56-58,79.  Weight torch layout (Cin,Cout,2,2,2).  g = INPUT geometry.
+size_t upconv2_pack_floats(int Cin, int Cout);
+int upconv2_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_bwd, hipStream_t s);
+int upconv2_fwd(int dtype, const void* x, int xcs, int Cin, const float* wp_fwd, const float* bias, void* y,
+                int ycs, int Cout, Geo g, hipStream_t s);
+size_t upconv2_bwd_ws_floats(int Cin, int Cout, Geo g);
+int upconv2_bwd(int dtype, const void* x, int xcs, int Cin, const void* gy, int gycs, int Cout,
+                const float* wp_bwd, void* dx, int dxcs, float* dW, float* db, int accumulate, float* ws,
+                size_t ws_floats, Geo g, hipStream_t s);
+
+// ---- final 1x1x1 conv, losses, metrics ------------------------------------------------ head_loss.hip
+// Reference: nn.Conv3d(16,4,1) models/unet.py:62,87 ; utils/metrics.py:14-40,65-129,137-190.
+int conv1_fwd(int dtype, const void* z, int zcs, int Cin, const float* w, const float* bias, float* logits,
+              int Cout, int N, int64_t V, hipStream_t s);
+size_t conv1_bwd_ws_floats(int Cin, int Cout);
+int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const float* dlogits, int Cout,
+              void* dz, int dzcs, float* dW, float* db, int accumulate, float* ws, int N, int64_t V,
+              hipStream_t s);
+
+struct LossCfg {
+    float w_ce;       // weight of mean cross-entropy
+    int region_kind;  // 0 none, 1 soft-Dice (combined_loss), 2 Tversky
+    float w_reg;      // weight of mean_{c>=1} region term
+    float alpha, beta, eps;
+    float w_kd;       // weight of T^2 * mean_{n,c,v} KL(teacher || student)   (0 = no distillation)
+    float temp;
+};
+enum { MI3D_MAX_CLASSES = 8 };
+size_t seg_loss_ws_bytes(int C);
+// loss_out: device float[1]; coef: device float[2*MI3D_MAX_CLASSES + 4] consumed by seg_loss_bwd
+int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
+                 LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s);
+int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
+                 LossCfg cfg, const float* coef, const float* grad_out, float* dlogits, hipStream_t s);
+size_t seg_metrics_ws_bytes(int C);
+// out: device float[3] = {iou, dice, acc}; Q1 loop bound = first spatial dim D (utils/metrics.py:74,101)
+int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,
+                void* ws, hipStream_t s);
+
+// ---- misc ---------------------------------------------------------------------------------- misc.hip
+int ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int dcs, int C, int N, int64_t V, hipStream_t s);
+int ndhwc_to_ncdhw(int dtype, const void* src, int scs, float* dst, int C, int N, int64_t V, hipStream_t s);
+// torch.mean(x, dim=[2,3,4]) models/unet_dann.py:79 ; backward adds scale*g[n,c]/V to every voxel
+int gap_fwd(int dtype, const void* z, int zcs, int C, int N, int64_t V, float* out, hipStream_t s);
+int gap_bwd(int dtype, const float* g, float scale, void* dz, int dzcs, int C, int N, int64_t V,
+            int accumulate, hipStream_t s);
+// nn.Linear (+ optional ReLU and dropout scale) train_dann.py:38-46 ; fp32, small M
+int linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
+               const float* drop, hipStream_t s);
+int linear_bwd(const float* x, const float* w, const float* y, const float* gy, int M, int K, int Nout,
+               int relu, const float* drop, float* gx, float* gw, float* gb, int accumulate, float gx_scale,
+               float* ws, hipStream_t s);
+int softmax_ce_rows(const float* logits, const int64_t* labels, int M, int C, float* loss, float* dlogits,
+                    float scale, hipStream_t s);
+// fused flat AdamW (torch.optim.AdamW semantics, train_unet.py:378); step_dev: device int64 step counter (incremented)
+int adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+               float eps, float wd, float grad_scale, int64_t* step_dev, hipStream_t s);
+// Dropout3d channel masks: out[i] = (u_i >= p) ? 1/(1-p) : 0, counter-based RNG; state_dev = {seed, counter}
+int dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, hipStream_t s);
+int fill_f32(float* p, int64_t n, float v, hipStream_t s);
+int scale_add_f32(float* dst, const float* src, int64_t n, float a, float b, hipStream_t s);  // dst = a*dst + b*src

@@ -1,0 +1,342 @@
+// plan.hip — whole-network execution plan for UNet3D: workspace layout + forward / backward kernel sequences.
+// One C call launches the entire forward (or a range of backward segments) on the caller's stream; nothing
+// here touches Python, allocates, or synchronises, so a step is hipGraph-capturable end to end.
+//
+// Reference: models/unet.py:34-90 (UNet3D), models/unet_dann.py:65-98 (GAP branch).
+// Data layout in HBM (all inside the caller-owned workspace, channels-last, dtype T):
+//   per DoubleConv half : y (raw conv output, kept for BN backward), stat[4][C]
+//   per block           : z1 (activated first half)
+//   per level l         : cat[l]  [N,V_l,2C_l]  = [ encoder output | upconv output ]   (torch.cat is free)
+//                         pool[l] [N,V_l/8,C_l]
+//   gradients           : gz[l], gcat[l], gp[l] per level + two max-size scratch tensors
+#include "../../include/mi3d.h"
+#include "ops.h"
+
+namespace {
+
+constexpr int MAXL = MI3D_MAX_LEVELS;
+
+struct HalfP {
+    int Cin, Cout;
+    size_t y, stat, wpf, wpd;     // byte offsets
+    int pidx, bidx;
+    int64_t drop_off;
+};
+struct BlockP {
+    int level;
+    HalfP h[2];
+    size_t z1;
+};
+struct Plan {
+    mi3d_unet_desc d;
+    int L, dt;
+    size_t esz;
+    int C[MAXL + 1];
+    Geo geo[MAXL + 1];
+    BlockP blk[2 * MAXL + 1];
+    int nblk;
+    size_t cat[MAXL], pool[MAXL], zb, zd[MAXL], upw[MAXL], xcl;
+    size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sC;
+    size_t bnws, wgws;
+    size_t wgws_floats;
+    size_t total;
+    int up_pidx(int i) const { return 8 * (L + 1) + 2 * i; }
+    int final_pidx() const { return 8 * (L + 1) + 2 * L + 8 * L; }
+};
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int build_plan(const mi3d_unet_desc* d, Plan& p) {
+    MI3D_CHECK_ARG(d != nullptr, "null descriptor");
+    MI3D_CHECK_ARG(d->n_levels >= 1 && d->n_levels <= MAXL, "n_levels=%d out of range", d->n_levels);
+    MI3D_CHECK_ARG(d->dtype == MI3D_F32 || d->dtype == MI3D_BF16, "bad dtype %d", d->dtype);
+    MI3D_CHECK_ARG(d->in_channels >= 1 && d->out_channels >= 1 && d->out_channels <= MI3D_MAX_CLASSES,
+                   "unsupported channel counts in=%d out=%d (out <= %d)", d->in_channels, d->out_channels, MI3D_MAX_CLASSES);
+    MI3D_CHECK_ARG(d->N >= 1 && d->D >= 1 && d->H >= 1 && d->W >= 1, "bad shape");
+    p.d = *d;
+    p.L = d->n_levels;
+    p.dt = d->dtype;
+    p.esz = d->dtype == MI3D_F32 ? 4 : 2;
+    int div = 1 << p.L;
+    // models/unet.py:81-83 falls back to F.interpolate when the sizes do not divide; not on any configured path
+    MI3D_CHECK_ARG(d->D % div == 0 && d->H % div == 0 && d->W % div == 0,
+                   "volume %dx%dx%d not divisible by 2^%d (nearest-interpolate fallback unsupported)", d->D, d->H, d->W, p.L);
+    for (int l = 0; l < p.L; l++) {
+        MI3D_CHECK_ARG(d->features[l] >= 1 && d->features[l] <= 256, "feature %d out of range", d->features[l]);
+        if (l > 0) MI3D_CHECK_ARG(d->features[l] == 2 * d->features[l - 1], "features must double per level");
+        p.C[l] = d->features[l];
+    }
+    p.C[p.L] = 2 * d->features[p.L - 1];
+    MI3D_CHECK_ARG(p.C[p.L] <= 256, "bottleneck width %d > 256", p.C[p.L]);
+    for (int l = 0; l <= p.L; l++) p.geo[l] = Geo{d->N, d->D >> l, d->H >> l, d->W >> l};
+
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    int64_t drop_off = 0;
+    size_t wg_floats = 0, maxCM = 0;
+    int maxC = 1;
+    p.nblk = 2 * p.L + 1;
+    for (int b = 0; b < p.nblk; b++) {
+        BlockP& B = p.blk[b];
+        int cin, cout;
+        if (b < p.L) { B.level = b; cin = b == 0 ? d->in_channels : p.C[b - 1]; cout = p.C[b]; }
+        else if (b == p.L) { B.level = p.L; cin = p.C[p.L - 1]; cout = p.C[p.L]; }
+        else { int i = b - p.L - 1; B.level = p.L - 1 - i; cin = 2 * p.C[B.level]; cout = p.C[B.level]; }
+        Geo g = p.geo[B.level];
+        int pbase = b <= p.L ? 8 * b : 8 * (p.L + 1) + 2 * p.L + 8 * (b - p.L - 1);
+        for (int h = 0; h < 2; h++) {
+            HalfP& H = B.h[h];
+            H.Cin = h == 0 ? cin : cout;
+            H.Cout = cout;
+            H.y = take((size_t)g.M() * cout * p.esz);
+            H.stat = take((size_t)4 * cout * sizeof(float));
+            H.wpf = take(conv3_direct_pack_floats(H.Cin, H.Cout) * sizeof(float));
+            H.wpd = take(conv3_direct_pack_floats(H.Cout, H.Cin) * sizeof(float));
+            H.pidx = pbase + 4 * h;
+            H.bidx = 6 * b + 3 * h;
+            H.drop_off = drop_off;
+            drop_off += (int64_t)d->N * cout;
+            size_t wf = conv3_direct_wgrad_ws_floats(H.Cin, H.Cout, g);
+            if (wf > wg_floats) wg_floats = wf;
+        }
+        B.z1 = take((size_t)g.M() * cout * p.esz);
+        if ((size_t)g.M() * cout > maxCM) maxCM = (size_t)g.M() * cout;
+        if (cout > maxC) maxC = cout;
+    }
+    for (int l = 0; l < p.L; l++) {
+        p.cat[l] = take((size_t)p.geo[l].M() * 2 * p.C[l] * p.esz);
+        p.pool[l] = take((size_t)p.geo[l + 1].M() * p.C[l] * p.esz);
+        p.gcat[l] = take((size_t)p.geo[l].M() * 2 * p.C[l] * p.esz);
+        p.gp[l] = take((size_t)p.geo[l + 1].M() * p.C[l] * p.esz);
+        p.gz[l] = take((size_t)p.geo[l].M() * p.C[l] * p.esz);
+    }
+    p.gz[p.L] = take((size_t)p.geo[p.L].M() * p.C[p.L] * p.esz);
+    p.zb = take((size_t)p.geo[p.L].M() * p.C[p.L] * p.esz);
+    for (int i = 0; i < p.L; i++) {
+        int l = p.L - 1 - i;
+        p.zd[i] = take((size_t)p.geo[l].M() * p.C[l] * p.esz);
+        p.upw[i] = take(upconv2_pack_floats(2 * p.C[l], p.C[l]) * sizeof(float));
+        size_t wf = upconv2_bwd_ws_floats(2 * p.C[l], p.C[l], p.geo[l + 1]);
+        if (wf > wg_floats) wg_floats = wf;
+    }
+    p.xcl = d->in_channels > 1 ? take((size_t)p.geo[0].M() * d->in_channels * p.esz) : 0;
+    size_t c1 = conv1_bwd_ws_floats(p.C[0], d->out_channels);
+    if (c1 > wg_floats) wg_floats = c1;
+    p.sB = take(maxCM * p.esz);
+    p.sC = take(maxCM * p.esz);
+    p.bnws = take(bn_ws_floats(maxC) * sizeof(float));
+    p.wgws_floats = wg_floats;
+    p.wgws = take(wg_floats * sizeof(float));
+    p.total = off;
+    return 0;
+}
+
+struct Ctx {
+    const Plan& p;
+    char* ws;
+    const void* const* params;
+    hipStream_t s;
+    template <typename T = void> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+    const float* P(int i) const { return reinterpret_cast<const float*>(params[i]); }
+};
+
+// input tensor of block b: pointer, channel stride, dtype
+void block_input(const Ctx& c, int b, const float* x, const void*& ptr, int& cs, int& dt) {
+    const Plan& p = c.p;
+    dt = p.dt;
+    if (b == 0) {
+        if (p.d.in_channels == 1) { ptr = x; cs = 1; dt = MI3D_F32; }
+        else { ptr = c.at(p.xcl); cs = p.d.in_channels; }
+    } else if (b <= p.L) { ptr = c.at(p.pool[b - 1]); cs = p.C[b - 1]; }
+    else { int l = p.blk[b].level; ptr = c.at(p.cat[l]); cs = 2 * p.C[l]; }
+}
+// output tensor (z2) of block b
+void block_output(const Ctx& c, int b, void*& ptr, int& cs) {
+    const Plan& p = c.p;
+    if (b < p.L) { ptr = c.at(p.cat[b]); cs = 2 * p.C[b]; }
+    else if (b == p.L) { ptr = c.at(p.zb); cs = p.C[p.L]; }
+    else { ptr = c.at(p.zd[b - p.L - 1]); cs = p.C[p.blk[b].level]; }
+}
+
+int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, const float* drop, int training) {
+    const Plan& p = c.p;
+    const BlockP& B = p.blk[b];
+    Geo g = p.geo[B.level];
+    const void* xin; int xcs, xdt;
+    block_input(c, b, x, xin, xcs, xdt);
+    void* zout; int zcs;
+    block_output(c, b, zout, zcs);
+    for (int h = 0; h < 2; h++) {
+        const HalfP& H = B.h[h];
+        MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), c.at<float>(H.wpd), c.s));
+        const void* in = h == 0 ? xin : c.at(B.z1);
+        int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
+        MI3D_TRY(conv3_direct_fwd(idt, p.dt, in, ics, H.Cin, c.at<float>(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout,
+                                  H.Cout, g, c.s));
+        float* rm = buffers ? (float*)buffers[H.bidx] : nullptr;
+        float* rv = buffers ? (float*)buffers[H.bidx + 1] : nullptr;
+        int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
+        if (training) {
+            MI3D_TRY(bn_train_stats(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt,
+                                    p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.at<float>(p.bnws), c.s));
+        } else {
+            MI3D_CHECK_ARG(rm && rv, "eval-mode forward needs running statistics");
+            MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
+        }
+        void* zo = h == 0 ? c.at(B.z1) : zout;
+        int zocs = h == 0 ? H.Cout : zcs;
+        MI3D_TRY(bn_apply_relu_drop(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
+                                    (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, c.s));
+    }
+    return 0;
+}
+
+// backward of block b given dz2 (dtype T, stride dzcs); writes dxin (may be NULL) with stride dxcs
+int block_backward(const Ctx& c, int b, const float* x, void* const* grads, const float* drop, const void* dz2,
+                   int dzcs, void* dxin, int dxcs, int accumulate) {
+    const Plan& p = c.p;
+    const BlockP& B = p.blk[b];
+    Geo g = p.geo[B.level];
+    const void* xin; int xcs, xdt;
+    block_input(c, b, x, xin, xcs, xdt);
+    float* wgws = c.at<float>(p.wgws);
+    auto G = [&](int i) { return grads ? (float*)grads[i] : nullptr; };
+    for (int h = 1; h >= 0; h--) {
+        const HalfP& H = B.h[h];
+        const void* dz = h == 1 ? dz2 : c.at(p.sC);
+        int dcs = h == 1 ? dzcs : H.Cout;
+        MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
+                        drop ? drop + H.drop_off : nullptr, c.at(p.sB), H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
+                        c.at<float>(p.bnws), c.s));
+        const void* in = h == 0 ? xin : c.at(B.z1);
+        int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
+        if (G(H.pidx) || G(H.pidx + 1))
+            MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
+                                        accumulate, wgws, p.wgws_floats, c.s));
+        void* dx = h == 1 ? c.at(p.sC) : dxin;
+        int dxs = h == 1 ? H.Cin : dxcs;
+        if (dx)
+            MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, c.at(p.sB), H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi3d_abi_version(void) { return 1; }
+
+int mi3d_unet_num_params(const mi3d_unet_desc* d) { return d ? 8 * (2 * d->n_levels + 1) + 2 * d->n_levels + 2 : -1; }
+int mi3d_unet_num_buffers(const mi3d_unet_desc* d) { return d ? 6 * (2 * d->n_levels + 1) : -1; }
+int mi3d_unet_num_segments(const mi3d_unet_desc* d) { return d ? 2 * d->n_levels + 2 : -1; }
+
+size_t mi3d_unet_workspace_bytes(const mi3d_unet_desc* d) {
+    Plan p;
+    if (build_plan(d, p) != 0) return 0;
+    return p.total;
+}
+
+int64_t mi3d_unet_dropout_count(const mi3d_unet_desc* d) {
+    Plan p;
+    if (build_plan(d, p) != 0) return -1;
+    const HalfP& last = p.blk[p.nblk - 1].h[1];
+    return last.drop_off + (int64_t)d->N * last.Cout;
+}
+
+int mi3d_unet_segment_params(const mi3d_unet_desc* d, int seg, int* r) {
+    Plan p;
+    MI3D_TRY(build_plan(d, p));
+    int L = p.L;
+    MI3D_CHECK_ARG(seg >= 0 && seg < 2 * L + 2 && r, "bad segment %d", seg);
+    r[2] = r[3] = -1;
+    if (seg == 0) { r[0] = p.final_pidx(); r[1] = r[0] + 2; }
+    else if (seg <= L) {
+        int i = L - seg;          // decoder.i and upconvs.i
+        r[0] = p.blk[L + 1 + i].h[0].pidx; r[1] = r[0] + 8;
+        r[2] = p.up_pidx(i); r[3] = r[2] + 2;
+    } else if (seg == L + 1) { r[0] = p.blk[L].h[0].pidx; r[1] = r[0] + 8; }
+    else { int l = 2 * L + 1 - seg; r[0] = p.blk[l].h[0].pidx; r[1] = r[0] + 8; }
+    return 0;
+}
+
+int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
+                      const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    Plan p;
+    MI3D_TRY(build_plan(d, p));
+    MI3D_CHECK_ARG(x && params && logits && workspace, "mi3d_unet_forward: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
+    MI3D_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
+    int L = p.L;
+    if (d->in_channels > 1)
+        MI3D_TRY(ncdhw_to_ndhwc(p.dt, x, c.at(p.xcl), d->in_channels, d->in_channels, d->N, p.geo[0].V(), c.s));
+    for (int l = 0; l < L; l++) {
+        MI3D_TRY(block_forward(c, l, x, buffers, drop_scales, training));
+        MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), 2 * p.C[l], p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
+    }
+    MI3D_TRY(block_forward(c, L, x, buffers, drop_scales, training));
+    if (gap_out) MI3D_TRY(gap_fwd(p.dt, c.at(p.zb), p.C[L], p.C[L], d->N, p.geo[L].V(), gap_out, c.s));
+    for (int i = 0; i < L; i++) {
+        int l = L - 1 - i;
+        float* wf = c.at<float>(p.upw[i]);
+        float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
+        MI3D_TRY(upconv2_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], wf, wb, c.s));
+        const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
+        char* catl = c.at<char>(p.cat[l]);
+        MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + (size_t)p.C[l] * p.esz,
+                             2 * p.C[l], p.C[l], p.geo[l + 1], c.s));
+        MI3D_TRY(block_forward(c, L + 1 + i, x, buffers, drop_scales, training));
+    }
+    MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
+                       d->out_channels, d->N, p.geo[0].V(), c.s));
+    return 0;
+}
+
+int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
+                       const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale, int accumulate,
+                       int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream) {
+    Plan p;
+    MI3D_TRY(build_plan(d, p));
+    MI3D_CHECK_ARG(x && params && grads && workspace, "mi3d_unet_backward: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
+    MI3D_CHECK_ARG(dlogits || dgap, "mi3d_unet_backward: neither dlogits nor dgap given");
+    int L = p.L, nseg = 2 * L + 2;
+    MI3D_CHECK_ARG(seg_begin >= 0 && seg_end <= nseg && seg_begin <= seg_end, "bad segment range [%d,%d)", seg_begin, seg_end);
+    Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
+    float* wgws = c.at<float>(p.wgws);
+    auto G = [&](int i) { return (float*)grads[i]; };
+    for (int seg = seg_begin; seg < seg_end; seg++) {
+        if (seg == 0) {
+            if (!dlogits) continue;
+            MI3D_TRY(conv1_bwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), dlogits, d->out_channels,
+                               c.at(p.gz[0]), p.C[0], G(p.final_pidx()), G(p.final_pidx() + 1), accumulate, wgws, d->N,
+                               p.geo[0].V(), c.s));
+        } else if (seg <= L) {
+            if (!dlogits) continue;
+            int l = seg - 1, i = L - 1 - l;       // decoder.i works at level l
+            MI3D_TRY(block_backward(c, L + 1 + i, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], c.at(p.gcat[l]), 2 * p.C[l], accumulate));
+            const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
+            float* wf = c.at<float>(p.upw[i]);
+            float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
+            char* gcatl = c.at<char>(p.gcat[l]);
+            MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gcatl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l], wb,
+                                 c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1), accumulate, wgws,
+                                 p.wgws_floats, p.geo[l + 1], c.s));
+        } else if (seg == L + 1) {
+            if (dgap)
+                MI3D_TRY(gap_bwd(p.dt, dgap, gap_scale, c.at(p.gz[L]), p.C[L], p.C[L], d->N, p.geo[L].V(), dlogits ? 1 : 0, c.s));
+            MI3D_TRY(block_backward(c, L, x, grads, drop_scales, c.at(p.gz[L]), p.C[L], c.at(p.gp[L - 1]), p.C[L - 1], accumulate));
+        } else {
+            int l = 2 * L + 1 - seg;              // encoder.l
+            MI3D_TRY(maxpool2_bwd(p.dt, c.at(p.gp[l]), p.C[l], c.at(p.cat[l]), 2 * p.C[l], dlogits ? c.at(p.gcat[l]) : nullptr,
+                                  2 * p.C[l], c.at(p.gz[l]), p.C[l], p.C[l], p.geo[l], c.s));
+            void* dx = l > 0 ? c.at(p.gp[l - 1]) : nullptr;
+            MI3D_TRY(block_backward(c, l, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], dx, l > 0 ? p.C[l - 1] : 0, accumulate));
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// pool.hip — MaxPool3d(kernel 2, stride 2) forward / backward on channels-last activations.
+// Reference: nn.MaxPool3d(2,2), models/unet.py:40,71.  Pure HBM streaming (8:1 read:write forward).
+// Backward routes the pooled gradient to the FIRST maximum in (d,h,w) scan order (torch semantics) and, in
+// the same pass, adds the gradient arriving through the skip connection (the torch.cat split of unet.py:84),
+// so the encoder output gradient is produced with one read of each operand and one write.
+#include "ops.h"
+
+namespace {
+constexpr int BLK = 256;
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void maxpool2_fwd_kernel(const T* __restrict__ z, int zcs, int C, int N, int D, int H, int W,
+                                                           T* __restrict__ p, int pcs) {
+    int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+    int64_t total = (int64_t)N * Do * Ho * Wo * G;
+    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+        int g = (int)(idx % G); int64_t r = idx / G;
+        int wo = (int)(r % Wo); r /= Wo; int ho = (int)(r % Ho); r /= Ho; int d_o = (int)(r % Do); int n = (int)(r / Do);
+        float m[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) m[i] = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    float v[VEC];
+                    ldv<T, VEC>(z + ((((int64_t)n * D + 2 * d_o + a) * H + 2 * ho + b) * W + 2 * wo + c) * zcs + g * VEC, v);
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) m[i] = v[i] > m[i] ? v[i] : m[i];
+                }
+        stv<T, VEC>(p + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * pcs + g * VEC, m);
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void maxpool2_bwd_kernel(const T* __restrict__ dp, int dpcs, const T* __restrict__ z, int zcs,
+                                                           const T* __restrict__ dskip, int dskipcs, T* __restrict__ dz,
+                                                           int dzcs, int C, int N, int D, int H, int W) {
+    int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+    int64_t total = (int64_t)N * Do * Ho * Wo * G;
+    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+        int g = (int)(idx % G); int64_t r = idx / G;
+        int wo = (int)(r % Wo); r /= Wo; int ho = (int)(r % Ho); r /= Ho; int d_o = (int)(r % Do); int n = (int)(r / Do);
+        float v[8][VEC], m[VEC], gp[VEC];
+        int arg[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { m[i] = -INFINITY; arg[i] = 0; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int a = k >> 2, b = (k >> 1) & 1, c = k & 1;
+            ldv<T, VEC>(z + ((((int64_t)n * D + 2 * d_o + a) * H + 2 * ho + b) * W + 2 * wo + c) * zcs + g * VEC, v[k]);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) if (v[k][i] > m[i]) { m[i] = v[k][i]; arg[i] = k; }
+        }
+        ldv<T, VEC>(dp + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * dpcs + g * VEC, gp);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int a = k >> 2, b = (k >> 1) & 1, c = k & 1;
+            int64_t off = (((int64_t)n * D + 2 * d_o + a) * H + 2 * ho + b) * W + 2 * wo + c;
+            float o[VEC];
+            if (dskip) ldv<T, VEC>(dskip + off * dskipcs + g * VEC, o);
+            else {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) o[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; i++) o[i] += (arg[i] == k) ? gp[i] : 0.f;
+            stv<T, VEC>(dz + off * dzcs + g * VEC, o);
+        }
+    }
+}
+
+inline int sgrid(int64_t total) {
+    int64_t w = (total + BLK - 1) / BLK;
+    return (int)(w < 1 ? 1 : (w > 2048 ? 2048 : w));
+}
+inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+}  // namespace
+
+int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int pcs, hipStream_t s) {
+    MI3D_CHECK_ARG(g.D % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0, "maxpool2: odd spatial size %dx%dx%d unsupported", g.D, g.H, g.W);
+    int64_t nout = g.M() / 8;
+    DISPATCH_T(dtype, T, {
+        if (C % 8 == 0 && zcs % 8 == 0 && pcs % 8 == 0 && al16(z) && al16(p))
+            maxpool2_fwd_kernel<T, 8><<<sgrid(nout * (C / 8)), BLK, 0, s>>>((const T*)z, zcs, C, g.N, g.D, g.H, g.W, (T*)p, pcs);
+        else
+            maxpool2_fwd_kernel<T, 1><<<sgrid(nout * C), BLK, 0, s>>>((const T*)z, zcs, C, g.N, g.D, g.H, g.W, (T*)p, pcs);
+        MI3D_LAUNCH_CHECK();
+    });
+    return 0;
+}
+
+int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs, void* dz,
+                 int dzcs, int C, Geo g, hipStream_t s) {
+    MI3D_CHECK_ARG(g.D % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0, "maxpool2_bwd: odd spatial size unsupported");
+    int64_t nout = g.M() / 8;
+    DISPATCH_T(dtype, T, {
+        bool v8 = C % 8 == 0 && zcs % 8 == 0 && dpcs % 8 == 0 && dzcs % 8 == 0 && (!dskip || dskipcs % 8 == 0) &&
+                  al16(z) && al16(dp) && al16(dz) && al16(dskip);
+        if (v8)
+            maxpool2_bwd_kernel<T, 8><<<sgrid(nout * (C / 8)), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);
+        else
+            maxpool2_bwd_kernel<T, 1><<<sgrid(nout * C), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);
+        MI3D_LAUNCH_CHECK();
+    });
+    return 0;
+}

@@ -1,0 +1,157 @@
+"""Drop-in mirror of the reference's utils/metrics.py loss / metric callables on the MI355X HIP path.
+
+  combined_loss(pred, target)                          utils/metrics.py:14-40
+  tversky_loss(pred, target, alpha, beta, epsilon)     :137-156
+  combined_ce_tversky_loss(pred, target, alpha, beta)  :158-167
+  distillation_loss(student, teacher, target, a, T)    :169-190
+  calculate_iou / calculate_dice / calculate_accuracy  :65-129  (incl. the reference's class-loop bound)
+  get_loss_fn(loss_type)                               train_unet.py:178-205
+
+pred (N,C,D,H,W) float, target (N,1,D,H,W) int64 -> 0-dim tensor, differentiable w.r.t. pred.  Each loss is ONE
+streaming forward kernel (+ a tiny finalize) and ONE backward kernel; the three metrics share ONE pass.
+Nothing here synchronises with the host: results stay on the device until the caller reads them.
+Deviation (documented): when no foreground class is present the reference returns the Python number 0 / 0.0;
+here a 0-dim tensor holding 0.0 is returned (same value through torch.as_tensor(.) / float(.)).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import LossCfg, call, ptr, stream_ptr
+
+# name: (w_ce, region_kind, w_reg, alpha, beta, eps)
+_KINDS = {
+    "combined": (1.0, 1, 1.0, 0.0, 0.0, 1e-5),
+    "dice": (0.0, 1, 1.0, 0.0, 0.0, 1e-5),
+}
+
+
+def _cfg(w_ce, kind, w_reg, alpha, beta, eps, w_kd=0.0, temp=1.0):
+    c = LossCfg()
+    c.w_ce, c.region_kind, c.w_reg, c.alpha, c.beta, c.eps, c.w_kd, c.temperature = (
+        w_ce, kind, w_reg, alpha, beta, eps, w_kd, temp)
+    return c
+
+
+def _prep(pred, target):
+    _lib.require_cuda(pred, "loss/metric")
+    if pred.dim() < 3:
+        raise _lib.Mi3dError(f"pred must be (N,C,spatial...), got {tuple(pred.shape)}")
+    n, c = pred.shape[0], pred.shape[1]
+    v = pred[0, 0].numel()
+    if target.numel() != n * v:
+        raise _lib.Mi3dError(f"target shape {tuple(target.shape)} does not match pred {tuple(pred.shape)}")
+    labels = target.reshape(n, v)
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    return n, c, v, labels.contiguous()
+
+
+class _SegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, labels, teacher, cfg, n, c, v):
+        p32 = pred.detach().contiguous().float()
+        t32 = teacher.detach().contiguous().float() if teacher is not None else None
+        dev = pred.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(_lib.LOSS_COEF_FLOATS, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib().mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=dev)
+        call("mi3d_seg_loss_forward", ptr(p32), ptr(labels), ptr(t32), n, c, v, C.byref(cfg), ptr(loss), ptr(coef),
+             ptr(ws), stream_ptr())
+        ctx.cfg, ctx.dims, ctx.in_dtype = cfg, (n, c, v), pred.dtype
+        ctx.save_for_backward(p32, labels, t32, coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p32, labels, t32, coef = ctx.saved_tensors
+        n, c, v = ctx.dims
+        g = g.contiguous().float()
+        d = torch.empty_like(p32)
+        call("mi3d_seg_loss_backward", ptr(p32), ptr(labels), ptr(t32), n, c, v, C.byref(ctx.cfg), ptr(coef), ptr(g),
+             ptr(d), stream_ptr())
+        if ctx.in_dtype != torch.float32:
+            d = d.to(ctx.in_dtype)
+        return d, None, None, None, None, None, None
+
+
+def _seg_loss(pred, target, cfg, teacher=None):
+    n, c, v, labels = _prep(pred, target)
+    return _SegLossFn.apply(pred, labels, teacher, cfg, n, c, v)
+
+
+def combined_loss(pred, target):
+    """CE(mean) + mean_{c>=1}(1 - (2 I_c + 1e-5)/(P_c + T_c + 1e-5))   [utils/metrics.py:14-40]"""
+    return _seg_loss(pred, target, _cfg(*_KINDS["combined"]))
+
+
+def dice_only_loss(pred, target):
+    """The 'dice' variant of get_loss_fn [train_unet.py:186-198]."""
+    return _seg_loss(pred, target, _cfg(*_KINDS["dice"]))
+
+
+def tversky_loss(pred, target, alpha=0.5, beta=0.5, epsilon=1e-6):
+    """[utils/metrics.py:137-156]"""
+    return _seg_loss(pred, target, _cfg(0.0, 2, 1.0, alpha, beta, epsilon))
+
+
+def combined_ce_tversky_loss(pred, target, alpha=0.7, beta=0.3):
+    """0.3*CE + 0.7*Tversky(alpha,beta)   [utils/metrics.py:158-167]"""
+    return _seg_loss(pred, target, _cfg(0.3, 2, 0.7, alpha, beta, 1e-6))
+
+
+def cross_entropy_loss(pred, target):
+    """Mean CE.  (The reference's get_loss_fn('ce') hands a (B,1,...) target to nn.CrossEntropyLoss and raises —
+    SURVEY Q5; here both (B,1,...) and (B,...) targets work.)"""
+    return _seg_loss(pred, target, _cfg(1.0, 0, 0.0, 0.0, 0.0, 1e-6))
+
+
+def distillation_loss(student_logits, teacher_logits, target, alpha=0.7, temperature=2.0):
+    """alpha*(0.3 CE + 0.7 Tversky(0.7,0.3)) + (1-alpha)*T^2*mean_{n,c,v} KL(teacher||student)  [metrics.py:169-190]"""
+    cfg = _cfg(0.3 * alpha, 2, 0.7 * alpha, 0.7, 0.3, 1e-6, 1.0 - alpha, temperature)
+    return _seg_loss(student_logits, target, cfg, teacher=teacher_logits)
+
+
+def get_loss_fn(loss_type):
+    """Mirror of train_unet.py:178-205."""
+    if loss_type == "ce":
+        return cross_entropy_loss
+    if loss_type == "tversky":
+        return lambda pred, target: tversky_loss(pred, target, alpha=0.5, beta=0.5)
+    if loss_type == "dice":
+        return dice_only_loss
+    if loss_type == "ce_tversky":
+        return lambda pred, target: combined_ce_tversky_loss(pred, target, alpha=0.5, beta=0.5)
+    return combined_loss
+
+
+# ---- metrics: one pass for all three, shared through a 1-entry cache ---------------------------------------
+_cache = {"key": None, "val": None}
+
+
+def calculate_all(pred, target):
+    """(iou, dice, accuracy) as a float32 tensor[3] from ONE argmax+count pass [utils/metrics.py:65-129]."""
+    n, c, v, labels = _prep(pred, target)
+    key = (pred.data_ptr(), pred._version, target.data_ptr(), target._version, tuple(pred.shape), pred.device)
+    if _cache["key"] == key:
+        return _cache["val"]
+    p32 = pred.detach().contiguous().float()
+    d = pred.shape[2] if pred.dim() > 2 else 1      # reference loop bound: first spatial dim after argmax
+    out = torch.empty(3, dtype=torch.float32, device=pred.device)
+    ws = torch.empty(_lib.lib().mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=pred.device)
+    call("mi3d_seg_metrics", ptr(p32), ptr(labels), n, c, d, v, ptr(out), ptr(ws), stream_ptr())
+    _cache["key"], _cache["val"] = key, out
+    return out
+
+
+def calculate_iou(pred, target):
+    return calculate_all(pred, target)[0]
+
+
+def calculate_dice(pred, target):
+    return calculate_all(pred, target)[1]
+
+
+def calculate_accuracy(pred, target):
+    return calculate_all(pred, target)[2]
