@@ -127,21 +127,27 @@ def get_loss_fn(loss_type):
 
 
 # ---- metrics: one pass for all three, shared through a 1-entry cache ---------------------------------------
-_cache = {"key": None, "val": None}
+import weakref
+
+_cache = {"pred": None, "target": None, "ver": None, "val": None}
 
 
 def calculate_all(pred, target):
-    """(iou, dice, accuracy) as a float32 tensor[3] from ONE argmax+count pass [utils/metrics.py:65-129]."""
+    """(iou, dice, accuracy) as a float32 tensor[3] from ONE argmax+count pass [utils/metrics.py:65-129].
+    The reference's three functions are called back to back on the same tensors (train_unet.py:229-232); the
+    result is shared between them while BOTH tensor objects are alive and unmodified (identity + version check)."""
     n, c, v, labels = _prep(pred, target)
-    key = (pred.data_ptr(), pred._version, target.data_ptr(), target._version, tuple(pred.shape), pred.device)
-    if _cache["key"] == key:
+    cp = _cache["pred"]() if _cache["pred"] is not None else None
+    ct = _cache["target"]() if _cache["target"] is not None else None
+    if cp is pred and ct is target and _cache["ver"] == (pred._version, target._version):
         return _cache["val"]
     p32 = pred.detach().contiguous().float()
     d = pred.shape[2] if pred.dim() > 2 else 1      # reference loop bound: first spatial dim after argmax
     out = torch.empty(3, dtype=torch.float32, device=pred.device)
     ws = torch.empty(_lib.lib().mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=pred.device)
     call("mi3d_seg_metrics", ptr(p32), ptr(labels), n, c, d, v, ptr(out), ptr(ws), stream_ptr())
-    _cache["key"], _cache["val"] = key, out
+    _cache["pred"], _cache["target"] = weakref.ref(pred), weakref.ref(target)
+    _cache["ver"], _cache["val"] = (pred._version, target._version), out
     return out
 
 

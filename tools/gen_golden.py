@@ -201,7 +201,7 @@ def gen_losses(ref_metrics, ref_train_unet, out):
 
 SLICE_KEYS = [
     "encoder.0.double_conv.0.weight", "encoder.0.double_conv.4.weight", "encoder.1.double_conv.0.weight",
-    "bottleneck.double_conv.4.bias", "upconvs.0.bias", "upconvs.3.weight", "decoder.3.double_conv.0.weight",
+    "bottleneck.double_conv.5.bias", "upconvs.0.bias", "upconvs.3.weight", "decoder.3.double_conv.0.weight",
     "decoder.3.double_conv.5.weight", "decoder.3.double_conv.5.bias", "final_conv.weight", "final_conv.bias",
     "encoder.0.double_conv.1.weight", "encoder.2.double_conv.5.bias", "decoder.0.double_conv.1.weight",
 ]
@@ -237,6 +237,22 @@ def gen_default_unet(ref_unet, ref_metrics, out):
         bn = {k: v for k, v in m.state_dict().items() if "running" in k}
         d[f"{tag}/bn_keys"] = np.array(sorted(bn.keys()))
         d[f"{tag}/bn_after1"] = np.concatenate([npy(bn[k]).ravel() for k in sorted(bn.keys())])
+        # the reference's own mixed-precision path (accelerate mixed_precision='bf16' == torch.autocast, train_unet.py:533)
+        # on the same weights/inputs: its deviation from fp32 is the yardstick for the bf16 HIP path's tolerance
+        fp32_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        torch.manual_seed(0)
+        m2 = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+        m2.train()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            lg2 = m2(x)
+        lg2 = lg2.float()
+        loss2 = ref_metrics.combined_loss(lg2, y)
+        loss2.backward()
+        rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+        d[f"{tag}/autocast_bf16/logits_relerr"] = np.asarray(rel(lg2.detach(), logits.detach()))
+        d[f"{tag}/autocast_bf16/loss"] = npy(loss2)
+        d[f"{tag}/autocast_bf16/dice"] = npy(ref_metrics.calculate_dice(lg2, y))
+        d[f"{tag}/autocast_bf16/grad_relerr"] = np.array([rel(p.grad, fp32_grads[k]) for k, p in m2.named_parameters()])
     # 5-step AdamW trajectory on a learnable (blocky) 16^3 N=2 problem; train_unet.py:378 defaults
     torch.manual_seed(0)
     m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
