@@ -1,6 +1,8 @@
 // api.hip — extern "C" wrappers (include/mi3d.h) around the per-operator launchers, losses, DANN head,
 // optimizer and hipGraph helpers.  The whole-network entry points live in plan.hip.
 #include "../../include/mi3d.h"
+#include <stdlib.h>
+
 #include "ops.h"
 
 static_assert(MI3D_LOSS_COEF_FLOATS >= 2 * MI3D_MAX_CLASSES + 4, "coef buffer too small");
@@ -10,6 +12,11 @@ static inline LossCfg to_cfg(const mi3d_loss_cfg* c) {
     k.w_ce = c->w_ce; k.region_kind = c->region_kind; k.w_reg = c->w_reg; k.alpha = c->alpha; k.beta = c->beta;
     k.eps = c->eps; k.w_kd = c->w_kd; k.temp = c->temperature > 0.f ? c->temperature : 1.f;
     return k;
+}
+
+static inline bool use_mfma(int in_dtype, int out_dtype, int Cin, int Cout, int xcs, int ycs) {
+    return in_dtype == MI3D_BF16 && out_dtype == MI3D_BF16 && conv3_mfma_supported(Cin, Cout, xcs, ycs) &&
+           !getenv("MI3D_FORCE_DIRECT");
 }
 
 extern "C" {
@@ -74,6 +81,10 @@ int mi3d_conv3_forward(int in_dtype, int out_dtype, const void* x, int xcs, int 
     float* wpf = (float*)workspace;
     float* wpd = wpf + conv3_direct_pack_floats(Cin, Cout);
     hipStream_t s = (hipStream_t)stream;
+    if (use_mfma(in_dtype, out_dtype, Cin, Cout, xcs, ycs)) {       // bf16 implicit GEMM on the matrix cores
+        MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, s));
+        return conv3_mfma_fwd(x, xcs, Cin, wpf, bias, y, ycs, Cout, Geo{N, D, H, W}, nullptr, s);
+    }
     MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
     return conv3_direct_fwd(in_dtype, out_dtype, x, xcs, Cin, wpf, bias, y, ycs, Cout, Geo{N, D, H, W}, s);
 }
@@ -87,8 +98,13 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
     float* wpd = wpf + conv3_direct_pack_floats(Cin, Cout);
     float* slabs = wpd + conv3_direct_pack_floats(Cout, Cin);
     hipStream_t s = (hipStream_t)stream;
-    MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
-    if (dx) MI3D_TRY(conv3_direct_fwd(dy_dtype, dy_dtype, dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, s));
+    if (dx && use_mfma(dy_dtype, dy_dtype, Cout, Cin, dycs, dxcs)) {
+        MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, s));
+        MI3D_TRY(conv3_mfma_fwd(dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, nullptr, s));
+    } else {
+        MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
+        if (dx) MI3D_TRY(conv3_direct_fwd(dy_dtype, dy_dtype, dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, s));
+    }
     if (dW || db)
         MI3D_TRY(conv3_direct_wgrad(x_dtype, dy_dtype, x, xcs, Cin, dy, dycs, Cout, g, dW, db, accumulate, slabs,
                                     conv3_direct_wgrad_ws_floats(Cin, Cout, g), s));

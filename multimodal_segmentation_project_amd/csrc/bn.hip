@@ -259,6 +259,14 @@ int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const fl
     return 0;
 }
 
+int bn_train_finalize(const float* part, int nblk, int C, int64_t M, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* stat,
+                      hipStream_t s) {
+    bn_stats_finalize_kernel<<<C, 64, 0, s>>>(part, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int bn_eval_stats(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                   float* stat, hipStream_t s) {
     bn_eval_stats_kernel<<<cdiv(C, 64), 64, 0, s>>>(C, gamma, beta, rm, rv, eps, stat);

@@ -25,6 +25,15 @@ int conv3_direct_wgrad(int x_dtype, int dy_dtype, const void* x, int xcs, int Ci
                        int Cout, Geo g, float* dW, float* db, int accumulate, float* ws, size_t ws_floats,
                        hipStream_t s);
 
+// ---- 3x3x3 convolution, MFMA implicit GEMM (bf16, Cin,Cout % 16 == 0) ------------------ conv3_mfma.hip
+bool conv3_mfma_supported(int Cin, int Cout, int xcs, int ycs);
+size_t conv3_mfma_pack_elems(int Cin, int Cout);             // bf16 elements of ONE packed operand
+int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, hipStream_t s);
+int conv3_mfma_stat_blocks(Geo g);                           // partials written when `part` != NULL
+// dgrad = same call with the dgrad pack and (Cin,Cout) swapped, bias NULL, part NULL
+int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
+                   Geo g, float* part, hipStream_t s);
+
 // ---- BatchNorm3d + ReLU + Dropout3d ---------------------------------------------------------- bn.hip
 // Reference: nn.BatchNorm3d / nn.ReLU(inplace) / nn.Dropout3d  models/unet.py:12-14,16-18.
 // stat buffer layout: float[4][C] = {mean, invstd, a = gamma*invstd, b = beta - mean*a}
@@ -32,6 +41,10 @@ size_t bn_ws_floats(int C);
 int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                    float eps, float* stat, float* ws, hipStream_t s);
+// same finalize, fed by conv-epilogue partials part[nblk][2][C]
+int bn_train_finalize(const float* part, int nblk, int C, int64_t M, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                      float eps, float* stat, hipStream_t s);
 int bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean,
                   const float* running_var, float eps, float* stat, hipStream_t s);
 // z = drop[n,c] * relu(a*y + b)      (drop == NULL -> 1)

@@ -10,6 +10,8 @@
 //                         pool[l] [N,V_l/8,C_l]
 //   gradients           : gz[l], gcat[l], gp[l] per level + two max-size scratch tensors
 #include "../../include/mi3d.h"
+#include <stdlib.h>
+
 #include "ops.h"
 
 namespace {
@@ -21,6 +23,7 @@ struct HalfP {
     size_t y, stat, wpf, wpd;     // byte offsets
     int pidx, bidx;
     int64_t drop_off;
+    bool mfma;                    // bf16 implicit-GEMM path (conv3_mfma.hip) vs direct fp32-FMA path
 };
 struct BlockP {
     int level;
@@ -37,7 +40,7 @@ struct Plan {
     int nblk;
     size_t cat[MAXL], pool[MAXL], zb, zd[MAXL], upw[MAXL], xcl;
     size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sC;
-    size_t bnws, wgws;
+    size_t bnws, wgws, statpart;
     size_t wgws_floats;
     size_t total;
     int up_pidx(int i) const { return 8 * (L + 1) + 2 * i; }
@@ -73,7 +76,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     int64_t drop_off = 0;
-    size_t wg_floats = 0, maxCM = 0;
+    size_t wg_floats = 0, maxCM = 0, statpart_floats = 1;
     int maxC = 1;
     p.nblk = 2 * p.L + 1;
     for (int b = 0; b < p.nblk; b++) {
@@ -90,8 +93,16 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
             H.Cout = cout;
             H.y = take((size_t)g.M() * cout * p.esz);
             H.stat = take((size_t)4 * cout * sizeof(float));
-            H.wpf = take(conv3_direct_pack_floats(H.Cin, H.Cout) * sizeof(float));
-            H.wpd = take(conv3_direct_pack_floats(H.Cout, H.Cin) * sizeof(float));
+            H.mfma = p.dt == MI3D_BF16 && conv3_mfma_supported(H.Cin, H.Cout, 16, 16) && !getenv("MI3D_FORCE_DIRECT");
+            if (H.mfma) {
+                H.wpf = take(conv3_mfma_pack_elems(H.Cin, H.Cout) * 2);
+                H.wpd = take(conv3_mfma_pack_elems(H.Cin, H.Cout) * 2);
+                size_t sp = (size_t)conv3_mfma_stat_blocks(g) * 2 * cout;
+                if (sp > statpart_floats) statpart_floats = sp;
+            } else {
+                H.wpf = take(conv3_direct_pack_floats(H.Cin, H.Cout) * sizeof(float));
+                H.wpd = take(conv3_direct_pack_floats(H.Cout, H.Cin) * sizeof(float));
+            }
             H.pidx = pbase + 4 * h;
             H.bidx = 6 * b + 3 * h;
             H.drop_off = drop_off;
@@ -125,6 +136,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     p.sB = take(maxCM * p.esz);
     p.sC = take(maxCM * p.esz);
     p.bnws = take(bn_ws_floats(maxC) * sizeof(float));
+    p.statpart = take(statpart_floats * sizeof(float));
     p.wgws_floats = wg_floats;
     p.wgws = take(wg_floats * sizeof(float));
     p.total = off;
@@ -168,15 +180,26 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
     block_output(c, b, zout, zcs);
     for (int h = 0; h < 2; h++) {
         const HalfP& H = B.h[h];
-        MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), c.at<float>(H.wpd), c.s));
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
-        MI3D_TRY(conv3_direct_fwd(idt, p.dt, in, ics, H.Cin, c.at<float>(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout,
-                                  H.Cout, g, c.s));
         float* rm = buffers ? (float*)buffers[H.bidx] : nullptr;
         float* rv = buffers ? (float*)buffers[H.bidx + 1] : nullptr;
         int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
-        if (training) {
+        bool fused_stats = false;
+        if (H.mfma) {
+            MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), c.s));
+            MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
+                                    training ? c.at<float>(p.statpart) : nullptr, c.s));
+            fused_stats = training;
+        } else {
+            MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), c.at<float>(H.wpd), c.s));
+            MI3D_TRY(conv3_direct_fwd(idt, p.dt, in, ics, H.Cin, c.at<float>(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout,
+                                      H.Cout, g, c.s));
+        }
+        if (fused_stats) {
+            MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), conv3_mfma_stat_blocks(g), H.Cout, g.M(), c.P(H.pidx + 2),
+                                       c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.s));
+        } else if (training) {
             MI3D_TRY(bn_train_stats(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt,
                                     p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.at<float>(p.bnws), c.s));
         } else {
@@ -215,8 +238,12 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
                                         accumulate, wgws, p.wgws_floats, c.s));
         void* dx = h == 1 ? c.at(p.sC) : dxin;
         int dxs = h == 1 ? H.Cin : dxcs;
-        if (dx)
-            MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, c.at(p.sB), H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
+        if (dx) {
+            if (H.mfma)
+                MI3D_TRY(conv3_mfma_fwd(c.at(p.sB), H.Cout, H.Cout, c.at(H.wpd), nullptr, dx, dxs, H.Cin, g, nullptr, c.s));
+            else
+                MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, c.at(p.sB), H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
+        }
     }
     return 0;
 }

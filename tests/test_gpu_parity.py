@@ -448,3 +448,38 @@ def test_determinism_and_scale_96(dtype):
     for a, b in zip(g1, g3):
         assert relerr((b / 2).cpu(), a.cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
     assert tuple(o1.shape) == (2, 4, 96, 96, 96) and o1.dtype == torch.float32
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 16, 5, 9, 17), (2, 32, 16, 6, 17, 35), (1, 16, 32, 4, 16, 48),
+                                   (1, 64, 32, 4, 8, 8), (1, 32, 64, 3, 6, 6), (1, 16, 16, 8, 16, 32)])
+def test_conv3_mfma_vs_c_oracle(orc, shape):
+    """bf16 MFMA implicit-GEMM conv (forward, input-gradient, weight-gradient) vs the C oracle on ragged volumes.
+    Inputs are small dyadic rationals (exact in bf16), so the only error is the final bf16 rounding of the output."""
+    from multimodal_segmentation_project_amd import _lib
+    from multimodal_segmentation_project_amd._lib import call, ptr
+    n, cin, cout, d, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.integers(-8, 9, (n, cin, d, h, w)).astype(np.float32) / 8
+    wgt = rng.integers(-8, 9, (cout, cin, 3, 3, 3)).astype(np.float32) / 16
+    b = rng.integers(-8, 9, cout).astype(np.float32) / 4
+    gy = rng.integers(-8, 9, (n, cout, d, h, w)).astype(np.float32) / 8
+    xcl = t(x.transpose(0, 2, 3, 4, 1)).bfloat16()
+    gcl = t(gy.transpose(0, 2, 3, 4, 1)).bfloat16()
+    wd, bd = t(wgt), t(b)
+    wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, h, w)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    y = torch.empty((n, d, h, w, cout), device=DEV, dtype=torch.bfloat16)
+    call("mi3d_conv3_forward", 1, 1, ptr(xcl), cin, cin, ptr(wd), ptr(bd), ptr(y), cout, cout, n, d, h, w, ptr(ws), wsb, None)
+    ref = orc.conv3d_fwd(x, wgt, b)
+    got = y.float().cpu().numpy().transpose(0, 4, 1, 2, 3)
+    assert np.abs(got - ref).max() <= np.abs(ref).max() * 2 ** -8 + 1e-6
+    dx = torch.empty_like(xcl)
+    dW = torch.empty((cout, cin, 3, 3, 3), device=DEV)
+    db = torch.empty(cout, device=DEV)
+    call("mi3d_conv3_backward", 1, 1, ptr(xcl), cin, cin, ptr(wd), ptr(gcl), cout, cout, ptr(dx), cin, ptr(dW), ptr(db), 0,
+         n, d, h, w, ptr(ws), wsb, None)
+    rgx, rgw, rgb = orc.conv3d_bwd(x, wgt, gy)
+    gotx = dx.float().cpu().numpy().transpose(0, 4, 1, 2, 3)
+    assert np.abs(gotx - rgx).max() <= np.abs(rgx).max() * 2 ** -8 + 1e-6
+    np.testing.assert_allclose(dW.cpu().numpy(), rgw, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), rgb, rtol=1e-5, atol=1e-3)
