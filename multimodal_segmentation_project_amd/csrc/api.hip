@@ -70,8 +70,10 @@ int mi3d_dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, voi
 // ---- per-operator entry points ------------------------------------------------------------------
 size_t mi3d_conv3_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W) {
     Geo g{N, D, H, W};
-    return (conv3_direct_pack_floats(Cin, Cout) + conv3_direct_pack_floats(Cout, Cin) +
-            conv3_direct_wgrad_ws_floats(Cin, Cout, g)) * sizeof(float);
+    size_t wg = conv3_direct_wgrad_ws_floats(Cin, Cout, g);
+    if (conv3_mfma_supported(Cin, Cout, 16, 16) && conv3_mfma_wgrad_ws_floats(Cin, Cout, g) > wg)
+        wg = conv3_mfma_wgrad_ws_floats(Cin, Cout, g);
+    return (conv3_direct_pack_floats(Cin, Cout) + conv3_direct_pack_floats(Cout, Cin) + wg) * sizeof(float);
 }
 int mi3d_conv3_forward(int in_dtype, int out_dtype, const void* x, int xcs, int Cin, const float* w, const float* bias,
                        void* y, int ycs, int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes,
@@ -105,9 +107,14 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
         MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
         if (dx) MI3D_TRY(conv3_direct_fwd(dy_dtype, dy_dtype, dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, s));
     }
-    if (dW || db)
-        MI3D_TRY(conv3_direct_wgrad(x_dtype, dy_dtype, x, xcs, Cin, dy, dycs, Cout, g, dW, db, accumulate, slabs,
-                                    conv3_direct_wgrad_ws_floats(Cin, Cout, g), s));
+    if (dW || db) {
+        if (use_mfma(x_dtype, dy_dtype, Cin, Cout, xcs, dycs) && dycs % 8 == 0)
+            MI3D_TRY(conv3_mfma_wgrad(x, xcs, Cin, dy, dycs, Cout, g, dW, db, accumulate, slabs,
+                                      conv3_mfma_wgrad_ws_floats(Cin, Cout, g), s));
+        else
+            MI3D_TRY(conv3_direct_wgrad(x_dtype, dy_dtype, x, xcs, Cin, dy, dycs, Cout, g, dW, db, accumulate, slabs,
+                                        conv3_direct_wgrad_ws_floats(Cin, Cout, g), s));
+    }
     return 0;
 }
 

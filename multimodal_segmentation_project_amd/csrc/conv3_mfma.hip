@@ -213,3 +213,213 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, s);
     return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, s);
 }
+
+// =================================================================================================== wgrad
+// dW[co][ci][tap] = sum_v dy[v][co] * x[v+tap][ci]   as   D[co][ci] += A[co][k] * B[k][ci],  k = voxel.
+// Both operands are channels-last in LDS ([voxel][16 ch], 32 B per voxel), i.e. K is the STRIDED index, so the
+// fragments are fetched with the CDNA4 transposing LDS read ds_read_b64_tr_b16 (4 voxels x 16 channels per 16-lane
+// group -> each lane gets 4 consecutive voxels of ITS channel); two reads make one 8-deep MFMA fragment.
+// One K-step = 32 voxels = 2 tile rows x 16 x-positions.  Wave w owns taps {w, w+4, ...} (7,7,7,6) for ALL voxels
+// (no cross-wave reduction); a workgroup owns CO_B x CI_B 16-channel blocks and sweeps tiles persistently, keeping
+// its 27 x CO_B x CI_B accumulator tiles in registers; the result goes to a per-workgroup slab (deterministic
+// fixed-order slab reduction afterwards, no float atomics).  Zero-filled staging makes ragged volumes exact.
+namespace {
+
+constexpr int WTZ = 4, WTY = 8, WTX = 16, WIZ = 6, WIY = 10, WIX = 18;
+constexpr int WNV = WTZ * WTY * WTX, WNH = WIZ * WIY * WIX;
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* base, int byteoff) {
+    // two transposed reads: voxels +0..3 and +4..7 (128 B further) of this lane group's 8-voxel run
+    auto* p0 = (lds_bf16x4*)(base + byteoff);
+    auto* p1 = (lds_bf16x4*)(base + byteoff + 128);
+    bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p0);
+    bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p1);
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <int CO_B, int CI_B>
+__global__ __launch_bounds__(BLK) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+                                                               const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
+                                                               int H, int W, int tilesZ, int tilesY, int tilesX,
+                                                               float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    bf16* dys = reinterpret_cast<bf16*>(lds_raw);                 // [CO_B][WNV][16]
+    bf16* xs = dys + CO_B * WNV * 16;                             // [CI_B][WNH][16]
+    const char* dysb = reinterpret_cast<const char*>(dys);
+    const char* xsb = reinterpret_cast<const char*>(xs);
+    int co0 = blockIdx.y * CO_B * 16, ci0 = blockIdx.z * CI_B * 16;
+    int lane = threadIdx.x & 63;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    int laneA = (((G >> 1) * WTX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
+    int laneB = (((G >> 1) * WIX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
+    int ntap = wave < 3 ? 7 : 6;
+    int tapOff[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        int t = wave + 4 * i;
+        t = t > 26 ? 26 : t;
+        tapOff[i] = (((t / 9) * WIY + ((t / 3) % 3)) * WIX + (t % 3)) * 32;
+    }
+    f32x4 acc[7][CO_B][CI_B];
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+#pragma unroll
+        for (int a = 0; a < CO_B; a++)
+#pragma unroll
+            for (int b = 0; b < CI_B; b++) acc[i][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbs[CO_B];
+#pragma unroll
+    for (int a = 0; a < CO_B; a++) dbs[a] = 0.f;
+
+    int ntiles = N * tilesZ * tilesY * tilesX;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        int tx_ = t % tilesX; t /= tilesX;
+        int ty_ = t % tilesY; t /= tilesY;
+        int tz_ = t % tilesZ; int n = t / tilesZ;
+        int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < CO_B * WNV * 2; idx += BLK) {
+            int half = idx & 1, vox = (idx >> 1) % WNV, cb = (idx >> 1) / WNV;
+            int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
+            int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gz < D && gy < H && gx < W)
+                v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)n * D + gz) * H + gy) * W + gx) * dycs + co0 + cb * 16 + half * 8);
+            *reinterpret_cast<bf16x8*>(dys + (cb * WNV + vox) * 16 + half * 8) = v;
+        }
+        for (int idx = threadIdx.x; idx < CI_B * WNH * 2; idx += BLK) {
+            int half = idx & 1, vox = (idx >> 1) % WNH, cb = (idx >> 1) / WNH;
+            int ix = vox % WIX, tt = vox / WIX, iy = tt % WIY, iz = tt / WIY;
+            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const bf16x8*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * xcs + ci0 + cb * 16 + half * 8);
+            *reinterpret_cast<bf16x8*>(xs + (cb * WNH + vox) * 16 + half * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+            int z = ks >> 2, yp = ks & 3;
+            bf16x8 A[CO_B];
+#pragma unroll
+            for (int a = 0; a < CO_B; a++) {
+                A[a] = tr_frag(dysb, laneA + ((z * WTY + 2 * yp) * WTX) * 32 + a * (WNV * 32));
+                if (wave == 0 && blockIdx.z == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) dbs[a] += (float)A[a][j];
+                }
+            }
+            int boff = laneB + ((z * WIY + 2 * yp) * WIX) * 32;
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                if (i < ntap) {
+#pragma unroll
+                    for (int b = 0; b < CI_B; b++) {
+                        bf16x8 B = tr_frag(xsb, boff + tapOff[i] + b * (WNH * 32));
+#pragma unroll
+                        for (int a = 0; a < CO_B; a++) acc[i][a][b] = mfma16(A[a], B, acc[i][a][b]);
+                    }
+                }
+            }
+        }
+    }
+    int64_t nW = (int64_t)Cout * Cin * 27;
+    float* slab = slabs + (int64_t)blockIdx.x * (nW + Cout);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        if (i < ntap) {
+            int t = wave + 4 * i;
+#pragma unroll
+            for (int a = 0; a < CO_B; a++)
+#pragma unroll
+                for (int b = 0; b < CI_B; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        int co = co0 + a * 16 + 4 * G + r, ci = ci0 + b * 16 + (lane & 15);
+                        slab[((int64_t)co * Cin + ci) * 27 + t] = acc[i][a][b][r];
+                    }
+        }
+    }
+    if (wave == 0 && blockIdx.z == 0) {
+#pragma unroll
+        for (int a = 0; a < CO_B; a++) {
+            float s = dbs[a];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < 16) slab[nW + co0 + a * 16 + lane] = s;
+        }
+    }
+}
+
+// fixed-order parallel slab sum: block = 32 elements x 8 slab groups
+__global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
+                                                           int64_t nW, float* __restrict__ dW, float* __restrict__ db,
+                                                           int accumulate) {
+    __shared__ float red[8][32];
+    int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    int64_t i = (int64_t)blockIdx.x * 32 + e;
+    float s = 0.f;
+    if (i < slab_sz)
+        for (int b = sg; b < nslab; b += 8) s += slabs[(int64_t)b * slab_sz + i];
+    red[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && i < slab_sz) {
+        float tsum = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        if (i < nW) { if (dW) dW[i] = accumulate ? dW[i] + tsum : tsum; }
+        else if (db) { db[i - nW] = accumulate ? db[i - nW] + tsum : tsum; }
+    }
+}
+
+inline int wgrad_mfma_nsb(int Cin, int Cout, Geo g) {
+    int cob = Cout % 32 == 0 ? 2 : 1, cib = Cin % 32 == 0 ? 2 : 1;
+    int groups = (Cout / (16 * cob)) * (Cin / (16 * cib));
+    int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
+    int64_t want = cdiv(512, groups);
+    return (int)(ntiles < want ? ntiles : want);
+}
+
+template <int CO_B, int CI_B>
+int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int Cout, Geo g, float* slabs, int nsb,
+                 hipStream_t s) {
+    static bool attr_set = false;
+    size_t lds = (size_t)(CO_B * WNV + CI_B * WNH) * 32;
+    if (!attr_set) {
+        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_mfma_kernel<CO_B, CI_B>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)nsb, (unsigned)(Cout / (16 * CO_B)), (unsigned)(Cin / (16 * CI_B)));
+    conv3_wgrad_mfma_kernel<CO_B, CI_B><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ),
+                                                              cdiv(g.H, WTY), cdiv(g.W, WTX), slabs);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g) {
+    return (size_t)wgrad_mfma_nsb(Cin, Cout, g) * ((size_t)Cout * Cin * 27 + Cout);
+}
+
+int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
+                     int accumulate, float* ws, size_t ws_floats, hipStream_t s) {
+    MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0, "conv3_mfma_wgrad: unsupported channels");
+    int nsb = wgrad_mfma_nsb(Cin, Cout, g);
+    int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
+    MI3D_CHECK_ARG(ws_floats >= (size_t)nsb * slab_sz, "conv3_mfma_wgrad: workspace too small");
+    const bf16* xp = (const bf16*)x; const bf16* dp = (const bf16*)dy;
+    bool co2 = Cout % 32 == 0, ci2 = Cin % 32 == 0;
+    int rc;
+    if (co2 && ci2) rc = launch_wgrad<2, 2>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
+    else if (co2) rc = launch_wgrad<2, 1>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
+    else if (ci2) rc = launch_wgrad<1, 2>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
+    else rc = launch_wgrad<1, 1>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
+    MI3D_TRY(rc);
+    slab_reduce2_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}

@@ -107,7 +107,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
             H.bidx = 6 * b + 3 * h;
             H.drop_off = drop_off;
             drop_off += (int64_t)d->N * cout;
-            size_t wf = conv3_direct_wgrad_ws_floats(H.Cin, H.Cout, g);
+            size_t wf = H.mfma ? conv3_mfma_wgrad_ws_floats(H.Cin, H.Cout, g) : conv3_direct_wgrad_ws_floats(H.Cin, H.Cout, g);
             if (wf > wg_floats) wg_floats = wf;
         }
         B.z1 = take((size_t)g.M() * cout * p.esz);
@@ -233,9 +233,14 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
                         c.at<float>(p.bnws), c.s));
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
-        if (G(H.pidx) || G(H.pidx + 1))
-            MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
-                                        accumulate, wgws, p.wgws_floats, c.s));
+        if (G(H.pidx) || G(H.pidx + 1)) {
+            if (H.mfma)
+                MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
+                                          wgws, p.wgws_floats, c.s));
+            else
+                MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
+                                            accumulate, wgws, p.wgws_floats, c.s));
+        }
         void* dx = h == 1 ? c.at(p.sC) : dxin;
         int dxs = h == 1 ? H.Cin : dxcs;
         if (dx) {
