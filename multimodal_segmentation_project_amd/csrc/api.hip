@@ -71,7 +71,7 @@ int mi3d_dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, voi
 size_t mi3d_conv3_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W) {
     Geo g{N, D, H, W};
     size_t wg = conv3_direct_wgrad_ws_floats(Cin, Cout, g);
-    if (conv3_mfma_supported(Cin, Cout, 16, 16) && conv3_mfma_wgrad_ws_floats(Cin, Cout, g) > wg)
+    if ((conv3_mfma_supported(Cin, Cout, 16, 16) || (Cin == 1 && Cout % 16 == 0)) && conv3_mfma_wgrad_ws_floats(Cin, Cout, g) > wg)
         wg = conv3_mfma_wgrad_ws_floats(Cin, Cout, g);
     return (conv3_direct_pack_floats(Cin, Cout) + conv3_direct_pack_floats(Cout, Cin) + wg) * sizeof(float);
 }
@@ -108,7 +108,11 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
         if (dx) MI3D_TRY(conv3_direct_fwd(dy_dtype, dy_dtype, dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, s));
     }
     if (dW || db) {
-        if (use_mfma(x_dtype, dy_dtype, Cin, Cout, xcs, dycs) && dycs % 8 == 0)
+        if (x_dtype == MI3D_F32 && dy_dtype == MI3D_BF16 && Cin == 1 && xcs == 1 && Cout % 16 == 0 && dycs % 8 == 0 &&
+            !getenv("MI3D_FORCE_DIRECT"))
+            MI3D_TRY(conv3_mfma_wgrad_c1((const float*)x, dy, dycs, Cout, g, dW, db, accumulate, slabs,
+                                         conv3_mfma_wgrad_ws_floats(Cin, Cout, g), s));
+        else if (use_mfma(x_dtype, dy_dtype, Cin, Cout, xcs, dycs) && dycs % 8 == 0)
             MI3D_TRY(conv3_mfma_wgrad(x, xcs, Cin, dy, dycs, Cout, g, dW, db, accumulate, slabs,
                                       conv3_mfma_wgrad_ws_floats(Cin, Cout, g), s));
         else

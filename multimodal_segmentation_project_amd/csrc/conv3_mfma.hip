@@ -219,10 +219,12 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
 // Both operands are channels-last in LDS ([voxel][16 ch], 32 B per voxel), i.e. K is the STRIDED index, so the
 // fragments are fetched with the CDNA4 transposing LDS read ds_read_b64_tr_b16 (4 voxels x 16 channels per 16-lane
 // group -> each lane gets 4 consecutive voxels of ITS channel); two reads make one 8-deep MFMA fragment.
-// One K-step = 32 voxels = 2 tile rows x 16 x-positions.  Wave w owns taps {w, w+4, ...} (7,7,7,6) for ALL voxels
-// (no cross-wave reduction); a workgroup owns CO_B x CI_B 16-channel blocks and sweeps tiles persistently, keeping
-// its 27 x CO_B x CI_B accumulator tiles in registers; the result goes to a per-workgroup slab (deterministic
-// fixed-order slab reduction afterwards, no float atomics).  Zero-filled staging makes ragged volumes exact.
+// One K-step = 32 voxels = 2 tile rows x 16 x-positions; wave w owns row pair w of every z-slice of the 4x8x16 tile.
+// A workgroup owns CO_B x CI_B 16-channel blocks x NT taps and sweeps tiles persistently with its NT*CO_B*CI_B
+// accumulator tiles in registers; waves are reduced through LDS once at the end and the result goes to one slab
+// per spatial workgroup (fixed-order slab sum afterwards: deterministic, no float atomics).  The (NT, #slabs) choice
+// keeps slab traffic below activation traffic: many slabs for the tiny-weight full-resolution layers, few slabs and
+// more tap/channel groups for the weight-heavy deep layers.  Zero-filled staging makes ragged volumes exact.
 namespace {
 
 constexpr int WTZ = 4, WTY = 8, WTX = 16, WIZ = 6, WIY = 10, WIX = 18;
@@ -239,43 +241,64 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base, int byteoff) {
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int CO_B, int CI_B>
+// reduce NTILE per-wave accumulator tiles across the 4 waves through LDS; `emit(idx, f32x4 sum)` is called by
+// wave (idx % 4) for tile idx
+template <int NTILE, typename Emit>
+__device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NTILE], float* red, int wave, int lane, Emit emit) {
+#pragma unroll
+    for (int base = 0; base < NTILE; base += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (base + j < NTILE) *reinterpret_cast<f32x4*>(red + ((j * 4 + wave) * 64 + lane) * 4) = acc[base + j];
+        __syncthreads();
+        int idx = base + wave;
+        if (idx < NTILE) {
+            f32x4 s = *reinterpret_cast<f32x4*>(red + ((wave * 4 + 0) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                f32x4 t = *reinterpret_cast<f32x4*>(red + ((wave * 4 + w) * 64 + lane) * 4);
+                s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+            }
+            emit(idx, s);
+        }
+    }
+}
+
+template <int CO_B, int CI_B, int NT>
 __global__ __launch_bounds__(BLK) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                                const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
-                                                               int H, int W, int tilesZ, int tilesY, int tilesX,
+                                                               int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
                                                                float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16* dys = reinterpret_cast<bf16*>(lds_raw);                 // [CO_B][WNV][16]
     bf16* xs = dys + CO_B * WNV * 16;                             // [CI_B][WNH][16]
     const char* dysb = reinterpret_cast<const char*>(dys);
     const char* xsb = reinterpret_cast<const char*>(xs);
+    int sb = blockIdx.x / TG, tg = blockIdx.x - sb * TG, nsb = gridDim.x / TG;
     int co0 = blockIdx.y * CO_B * 16, ci0 = blockIdx.z * CI_B * 16;
     int lane = threadIdx.x & 63;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    int laneA = (((G >> 1) * WTX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
-    int laneB = (((G >> 1) * WIX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
-    int ntap = wave < 3 ? 7 : 6;
-    int tapOff[7];
+    int laneA = (((2 * wave + (G >> 1)) * WTX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
+    int laneB = (((2 * wave + (G >> 1)) * WIX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
+    int tapOff[NT];
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        int t = wave + 4 * i;
-        t = t > 26 ? 26 : t;
+    for (int i = 0; i < NT; i++) {
+        int t = tg * NT + i;
         tapOff[i] = (((t / 9) * WIY + ((t / 3) % 3)) * WIX + (t % 3)) * 32;
     }
-    f32x4 acc[7][CO_B][CI_B];
+    constexpr int NTILE = NT * CO_B * CI_B;
+    f32x4 acc[NTILE];
 #pragma unroll
-    for (int i = 0; i < 7; i++)
-#pragma unroll
-        for (int a = 0; a < CO_B; a++)
-#pragma unroll
-            for (int b = 0; b < CI_B; b++) acc[i][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NTILE; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbs[CO_B];
 #pragma unroll
     for (int a = 0; a < CO_B; a++) dbs[a] = 0.f;
+    bool do_db = (tg == 0 && blockIdx.z == 0);
 
     int ntiles = N * tilesZ * tilesY * tilesX;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = sb; tile < ntiles; tile += nsb) {
         int t = tile;
         int tx_ = t % tilesX; t /= tilesX;
         int ty_ = t % tilesY; t /= tilesY;
@@ -302,57 +325,140 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_mfma_kernel(const bf16* __res
         }
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < 16; ks++) {
-            int z = ks >> 2, yp = ks & 3;
+        for (int z = 0; z < WTZ; z++) {
             bf16x8 A[CO_B];
 #pragma unroll
             for (int a = 0; a < CO_B; a++) {
-                A[a] = tr_frag(dysb, laneA + ((z * WTY + 2 * yp) * WTX) * 32 + a * (WNV * 32));
-                if (wave == 0 && blockIdx.z == 0) {
+                A[a] = tr_frag(dysb, laneA + z * (WTY * WTX * 32) + a * (WNV * 32));
+                if (do_db) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) dbs[a] += (float)A[a][j];
                 }
             }
-            int boff = laneB + ((z * WIY + 2 * yp) * WIX) * 32;
+            int boff = laneB + z * (WIY * WIX * 32);
 #pragma unroll
-            for (int i = 0; i < 7; i++) {
-                if (i < ntap) {
+            for (int i = 0; i < NT; i++)
 #pragma unroll
-                    for (int b = 0; b < CI_B; b++) {
-                        bf16x8 B = tr_frag(xsb, boff + tapOff[i] + b * (WNH * 32));
+                for (int b = 0; b < CI_B; b++) {
+                    bf16x8 B = tr_frag(xsb, boff + tapOff[i] + b * (WNH * 32));
 #pragma unroll
-                        for (int a = 0; a < CO_B; a++) acc[i][a][b] = mfma16(A[a], B, acc[i][a][b]);
-                    }
+                    for (int a = 0; a < CO_B; a++)
+                        acc[(i * CO_B + a) * CI_B + b] = mfma16(A[a], B, acc[(i * CO_B + a) * CI_B + b]);
                 }
-            }
         }
     }
     int64_t nW = (int64_t)Cout * Cin * 27;
-    float* slab = slabs + (int64_t)blockIdx.x * (nW + Cout);
+    float* slab = slabs + (int64_t)sb * (nW + Cout);
+    float* red = reinterpret_cast<float*>(lds_raw);
+    reduce_waves<NTILE>(acc, red, wave, lane, [&](int idx, f32x4 sum) {
+        int b = idx % CI_B, a = (idx / CI_B) % CO_B, i = idx / (CI_B * CO_B);
+        int tap = tg * NT + i;
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        if (i < ntap) {
-            int t = wave + 4 * i;
-#pragma unroll
-            for (int a = 0; a < CO_B; a++)
-#pragma unroll
-                for (int b = 0; b < CI_B; b++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        int co = co0 + a * 16 + 4 * G + r, ci = ci0 + b * 16 + (lane & 15);
-                        slab[((int64_t)co * Cin + ci) * 27 + t] = acc[i][a][b][r];
-                    }
+        for (int r = 0; r < 4; r++) {
+            int co = co0 + a * 16 + 4 * G + r, ci = ci0 + b * 16 + (lane & 15);
+            slab[((int64_t)co * Cin + ci) * 27 + tap] = sum[r];
         }
-    }
-    if (wave == 0 && blockIdx.z == 0) {
+    });
+    if (do_db) {
+        __syncthreads();
 #pragma unroll
         for (int a = 0; a < CO_B; a++) {
-            float s = dbs[a];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (lane < 16) slab[nW + co0 + a * 16 + lane] = s;
+            float sv = dbs[a];
+            sv += __shfl_xor(sv, 16, 64);
+            sv += __shfl_xor(sv, 32, 64);
+            if (lane < 16) red[(a * 4 + wave) * 16 + lane] = sv;
+        }
+        __syncthreads();
+        if (threadIdx.x < CO_B * 16) {
+            int a = threadIdx.x / 16, c = threadIdx.x % 16;
+            slab[nW + co0 + threadIdx.x] = (red[(a * 4 + 0) * 16 + c] + red[(a * 4 + 1) * 16 + c]) +
+                                           (red[(a * 4 + 2) * 16 + c] + red[(a * 4 + 3) * 16 + c]);
         }
     }
+}
+
+// ---- first layer (Cin = 1, fp32 input): dW[co][0][tap] = sum_v dy[v][co] * x[v+tap].  N-dimension = the 27 taps
+// (two 16-column MFMAs); the B fragment of a lane is 8 consecutive x-positions of ONE tap, read as one aligned
+// ds_read_b128 from a tile stored three times, pre-shifted by dx = 0,1,2.
+constexpr int C1_ROWS = WIZ * WIY;     // 60 halo rows of 16 positions
+__global__ __launch_bounds__(BLK) void conv3_wgrad_c1_kernel(const float* __restrict__ x, const bf16* __restrict__ dy, int dycs,
+                                                             int Cout, int N, int D, int H, int W, int tilesZ, int tilesY,
+                                                             int tilesX, float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) bf16 dys[WNV * 16];
+    __shared__ __attribute__((aligned(16))) bf16 xsh[3 * C1_ROWS * 16];
+    __shared__ __attribute__((aligned(16))) float red[16 * 64 * 4];
+    const char* dysb = reinterpret_cast<const char*>(dys);
+    int co0 = blockIdx.y * 16;
+    int lane = threadIdx.x & 63;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, nn = lane & 15;
+    int laneA = (((2 * wave + (G >> 1)) * WTX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
+    // B: tap t = nn + 16*h ; element offset of (dx, dz, dy) inside xsh for this lane's row pair / half row
+    int offB[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        int t = nn + 16 * h;
+        t = t > 26 ? 26 : t;
+        int dz = t / 9, dyy = (t / 3) % 3, dx = t % 3;
+        offB[h] = ((dx * WIZ + dz) * WIY + (2 * wave + (G >> 1) + dyy)) * 16 + 8 * (G & 1);
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float dbs = 0.f;
+    int ntiles = N * tilesZ * tilesY * tilesX;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        int tx_ = t % tilesX; t /= tilesX;
+        int ty_ = t % tilesY; t /= tilesY;
+        int tz_ = t % tilesZ; int n = t / tilesZ;
+        int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < WNV * 2; idx += BLK) {
+            int half = idx & 1, vox = idx >> 1;
+            int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
+            int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gz < D && gy < H && gx < W)
+                v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)n * D + gz) * H + gy) * W + gx) * dycs + co0 + half * 8);
+            *reinterpret_cast<bf16x8*>(dys + vox * 16 + half * 8) = v;
+        }
+        for (int idx = threadIdx.x; idx < 3 * C1_ROWS * 16; idx += BLK) {
+            int xx = idx & 15, row = (idx >> 4) % C1_ROWS, dx = idx / (16 * C1_ROWS);
+            int iy = row % WIY, iz = row / WIY;
+            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + xx + dx;
+            float v = 0.f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[(((int64_t)n * D + gz) * H + gy) * W + gx];
+            xsh[idx] = (bf16)v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int z = 0; z < WTZ; z++) {
+            bf16x8 A = tr_frag(dysb, laneA + z * (WTY * WTX * 32));
+#pragma unroll
+            for (int j = 0; j < 8; j++) dbs += (float)A[j];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                bf16x8 B = *reinterpret_cast<const bf16x8*>(xsh + offB[h] + z * (WIY * 16));
+                acc[h] = mfma16(A, B, acc[h]);
+            }
+        }
+    }
+    int64_t nW = (int64_t)Cout * 27;
+    float* slab = slabs + (int64_t)blockIdx.x * (nW + Cout);
+    reduce_waves<2>(acc, red, wave, lane, [&](int idx, f32x4 sum) {
+        int tap = nn + 16 * idx;
+        if (tap < 27) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) slab[(int64_t)(co0 + 4 * G + r) * 27 + tap] = sum[r];
+        }
+    });
+    __syncthreads();
+    float sv = dbs;
+    sv += __shfl_xor(sv, 16, 64);
+    sv += __shfl_xor(sv, 32, 64);
+    if (lane < 16) red[wave * 16 + lane] = sv;
+    __syncthreads();
+    if (threadIdx.x < 16)
+        slab[nW + co0 + threadIdx.x] = (red[threadIdx.x] + red[16 + threadIdx.x]) + (red[32 + threadIdx.x] + red[48 + threadIdx.x]);
 }
 
 // fixed-order parallel slab sum: block = 32 elements x 8 slab groups
@@ -374,51 +480,83 @@ __global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restri
     }
 }
 
-inline int wgrad_mfma_nsb(int Cin, int Cout, Geo g) {
-    int cob = Cout % 32 == 0 ? 2 : 1, cib = Cin % 32 == 0 ? 2 : 1;
-    int groups = (Cout / (16 * cob)) * (Cin / (16 * cib));
+struct WgCfg { int cob, cib, nt, tg, nsb; };
+
+inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
+    WgCfg c;
+    c.cob = Cout % 32 == 0 ? 2 : 1;
+    c.cib = Cin % 32 == 0 ? 2 : 1;
+    int groups = (Cout / (16 * c.cob)) * (Cin / (16 * c.cib));
     int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
-    int64_t want = cdiv(512, groups);
-    return (int)(ntiles < want ? ntiles : want);
+    int blocks = c.cob * c.cib;
+    c.nt = blocks == 1 ? 27 : (blocks == 2 ? 9 : ((ntiles * groups >= 768) ? 9 : 3));
+    c.tg = 27 / c.nt;
+    int64_t want = cdiv(512, (int64_t)groups * c.tg);
+    if (want < 1) want = 1;
+    c.nsb = (int)(ntiles < want ? ntiles : want);
+    return c;
 }
 
-template <int CO_B, int CI_B>
-int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int Cout, Geo g, float* slabs, int nsb,
+template <int CO_B, int CI_B, int NT>
+int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int Cout, Geo g, float* slabs, WgCfg c,
                  hipStream_t s) {
     static bool attr_set = false;
     size_t lds = (size_t)(CO_B * WNV + CI_B * WNH) * 32;
+    if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
     if (!attr_set) {
-        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_mfma_kernel<CO_B, CI_B>),
+        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_mfma_kernel<CO_B, CI_B, NT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((unsigned)nsb, (unsigned)(Cout / (16 * CO_B)), (unsigned)(Cin / (16 * CI_B)));
-    conv3_wgrad_mfma_kernel<CO_B, CI_B><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ),
-                                                              cdiv(g.H, WTY), cdiv(g.W, WTX), slabs);
+    dim3 grid((unsigned)(c.nsb * c.tg), (unsigned)(Cout / (16 * CO_B)), (unsigned)(Cin / (16 * CI_B)));
+    conv3_wgrad_mfma_kernel<CO_B, CI_B, NT><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W,
+                                                                  cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs);
     MI3D_LAUNCH_CHECK();
     return 0;
+}
+
+inline int c1_nsb(Geo g) {
+    int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
+    return (int)(ntiles < 1024 ? ntiles : 1024);
 }
 
 }  // namespace
 
 size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g) {
-    return (size_t)wgrad_mfma_nsb(Cin, Cout, g) * ((size_t)Cout * Cin * 27 + Cout);
+    if (Cin == 1) return (size_t)c1_nsb(g) * ((size_t)Cout * 27 + Cout);
+    return (size_t)wgrad_cfg(Cin, Cout, g).nsb * ((size_t)Cout * Cin * 27 + Cout);
 }
 
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
                      int accumulate, float* ws, size_t ws_floats, hipStream_t s) {
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0, "conv3_mfma_wgrad: unsupported channels");
-    int nsb = wgrad_mfma_nsb(Cin, Cout, g);
+    WgCfg c = wgrad_cfg(Cin, Cout, g);
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
-    MI3D_CHECK_ARG(ws_floats >= (size_t)nsb * slab_sz, "conv3_mfma_wgrad: workspace too small");
+    MI3D_CHECK_ARG(ws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_wgrad: workspace too small");
     const bf16* xp = (const bf16*)x; const bf16* dp = (const bf16*)dy;
-    bool co2 = Cout % 32 == 0, ci2 = Cin % 32 == 0;
     int rc;
-    if (co2 && ci2) rc = launch_wgrad<2, 2>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
-    else if (co2) rc = launch_wgrad<2, 1>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
-    else if (ci2) rc = launch_wgrad<1, 2>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
-    else rc = launch_wgrad<1, 1>(xp, xcs, Cin, dp, dycs, Cout, g, ws, nsb, s);
+    if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else if (c.cob == 1 && c.cib == 2) rc = launch_wgrad<1, 2, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else if (c.nt == 9) rc = launch_wgrad<2, 2, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else rc = launch_wgrad<2, 2, 3>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
     MI3D_TRY(rc);
+    slab_reduce2_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// first layer: x fp32 single channel (N,D,H,W), dy bf16 channels-last, Cout % 16 == 0
+int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db, int accumulate,
+                        float* ws, size_t ws_floats, hipStream_t s) {
+    MI3D_CHECK_ARG(Cout % 16 == 0 && dycs % 8 == 0, "conv3_mfma_wgrad_c1: unsupported channels");
+    int nsb = c1_nsb(g);
+    int64_t nW = (int64_t)Cout * 27, slab_sz = nW + Cout;
+    MI3D_CHECK_ARG(ws_floats >= (size_t)nsb * slab_sz, "conv3_mfma_wgrad_c1: workspace too small");
+    dim3 grid((unsigned)nsb, (unsigned)(Cout / 16));
+    conv3_wgrad_c1_kernel<<<grid, BLK, 0, s>>>(x, (const bf16*)dy, dycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ), cdiv(g.H, WTY),
+                                               cdiv(g.W, WTX), ws);
+    MI3D_LAUNCH_CHECK();
     slab_reduce2_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
     MI3D_LAUNCH_CHECK();
     return 0;

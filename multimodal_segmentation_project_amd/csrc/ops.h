@@ -38,6 +38,9 @@ size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
                      int accumulate, float* ws, size_t ws_floats, hipStream_t s);
 
+int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db, int accumulate,
+                        float* ws, size_t ws_floats, hipStream_t s);
+
 // ---- BatchNorm3d + ReLU + Dropout3d ---------------------------------------------------------- bn.hip
 // Reference: nn.BatchNorm3d / nn.ReLU(inplace) / nn.Dropout3d  models/unet.py:12-14,16-18.
 // stat buffer layout: float[4][C] = {mean, invstd, a = gamma*invstd, b = beta - mean*a}

@@ -107,7 +107,8 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
             H.bidx = 6 * b + 3 * h;
             H.drop_off = drop_off;
             drop_off += (int64_t)d->N * cout;
-            size_t wf = H.mfma ? conv3_mfma_wgrad_ws_floats(H.Cin, H.Cout, g) : conv3_direct_wgrad_ws_floats(H.Cin, H.Cout, g);
+            bool c1 = p.dt == MI3D_BF16 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT");
+            size_t wf = (H.mfma || c1) ? conv3_mfma_wgrad_ws_floats(H.Cin, H.Cout, g) : conv3_direct_wgrad_ws_floats(H.Cin, H.Cout, g);
             if (wf > wg_floats) wg_floats = wf;
         }
         B.z1 = take((size_t)g.M() * cout * p.esz);
@@ -237,6 +238,9 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             if (H.mfma)
                 MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
                                           wgws, p.wgws_floats, c.s));
+            else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT"))
+                MI3D_TRY(conv3_mfma_wgrad_c1((const float*)in, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
+                                             wgws, p.wgws_floats, c.s));
             else
                 MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
                                             accumulate, wgws, p.wgws_floats, c.s));

@@ -483,3 +483,27 @@ def test_conv3_mfma_vs_c_oracle(orc, shape):
     assert np.abs(gotx - rgx).max() <= np.abs(rgx).max() * 2 ** -8 + 1e-6
     np.testing.assert_allclose(dW.cpu().numpy(), rgw, rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), rgb, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 5, 9, 17), (2, 16, 8, 16, 32), (1, 32, 4, 8, 16)])
+def test_conv3_first_layer_wgrad_mfma(orc, shape):
+    """First layer (Cin=1, fp32 image, bf16 dy): weight/bias gradient on the matrix cores vs the C oracle."""
+    from multimodal_segmentation_project_amd import _lib
+    from multimodal_segmentation_project_amd._lib import call, ptr
+    n, cout, d, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.integers(-8, 9, (n, 1, d, h, w)).astype(np.float32) / 8
+    wgt = rng.integers(-8, 9, (cout, 1, 3, 3, 3)).astype(np.float32) / 16
+    gy = rng.integers(-8, 9, (n, cout, d, h, w)).astype(np.float32) / 8
+    xd = t(x)
+    gcl = t(gy.transpose(0, 2, 3, 4, 1)).bfloat16()
+    wd = t(wgt)
+    wsb = _lib.lib().mi3d_conv3_workspace_bytes(1, cout, n, d, h, w)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dW = torch.empty((cout, 1, 3, 3, 3), device=DEV)
+    db = torch.empty(cout, device=DEV)
+    call("mi3d_conv3_backward", 0, 1, ptr(xd), 1, 1, ptr(wd), ptr(gcl), cout, cout, None, 1, ptr(dW), ptr(db), 0,
+         n, d, h, w, ptr(ws), wsb, None)
+    _, rgw, rgb = orc.conv3d_bwd(x, wgt, gy)
+    np.testing.assert_allclose(dW.cpu().numpy(), rgw, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), rgb, rtol=1e-5, atol=1e-3)
