@@ -81,18 +81,33 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
 #pragma unroll
         for (int c = 0; c < COB; c++) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // staging map: each thread moves NIT 16-byte pieces (voxel, channel half) per chunk; the voxel -> global offset map
+    // is chunk-invariant, so it is computed once (-1 = outside the volume -> zero fill)
+    constexpr int NIT = (NVOX * 2 + BLK - 1) / BLK;
+    int soff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int idx = threadIdx.x + it * BLK;
+        int vox = idx >> 1, half = idx & 1;
+        int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+        int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+        bool inb = idx < NVOX * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        soff[it] = inb ? ((gz * H + gy) * W + gx) * xcs + half * 8 : -1;
+    }
+    const bf16* xn = x + (int64_t)n * D * H * W * xcs;
     int nchunk = Cin / 16;
     for (int chunk = 0; chunk < nchunk; chunk++) {
+        bf16x8 sv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + chunk * 16);
+        }
         __syncthreads();
-        // ---- stage the halo tile of this 16-channel chunk: 2 x 16-B pieces per voxel, zero fill outside the volume
-        for (int idx = threadIdx.x; idx < NVOX * 2; idx += BLK) {
-            int vox = idx >> 1, half = idx & 1;
-            int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
-            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const bf16x8*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * xcs + chunk * 16 + half * 8);
-            *reinterpret_cast<bf16x8*>(xs + vox * 16 + half * 8) = v;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            int idx = threadIdx.x + it * BLK;
+            if (idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = sv[it];
         }
         __syncthreads();
         const bf16* wc = wp + ((int64_t)chunk * 14 * nCobTotal + cobBase) * 512 + lane * 8;
@@ -304,24 +319,42 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_mfma_kernel(const bf16* __res
         int ty_ = t % tilesY; t /= tilesY;
         int tz_ = t % tilesZ; int n = t / tilesZ;
         int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < CO_B * WNV * 2; idx += BLK) {
-            int half = idx & 1, vox = (idx >> 1) % WNV, cb = (idx >> 1) / WNV;
-            int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
-            int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gz < D && gy < H && gx < W)
-                v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)n * D + gz) * H + gy) * W + gx) * dycs + co0 + cb * 16 + half * 8);
-            *reinterpret_cast<bf16x8*>(dys + (cb * WNV + vox) * 16 + half * 8) = v;
-        }
-        for (int idx = threadIdx.x; idx < CI_B * WNH * 2; idx += BLK) {
-            int half = idx & 1, vox = (idx >> 1) % WNH, cb = (idx >> 1) / WNH;
-            int ix = vox % WIX, tt = vox / WIX, iy = tt % WIY, iz = tt / WIY;
-            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const bf16x8*>(x + ((((int64_t)n * D + gz) * H + gy) * W + gx) * xcs + ci0 + cb * 16 + half * 8);
-            *reinterpret_cast<bf16x8*>(xs + (cb * WNH + vox) * 16 + half * 8) = v;
+        {
+            constexpr int NA = (CO_B * WNV * 2 + BLK - 1) / BLK, NB = (CI_B * WNH * 2 + BLK - 1) / BLK;
+            bf16x8 va[NA], vb[NB];
+            const bf16* dyn = dy + (int64_t)n * D * H * W * dycs + co0;
+            const bf16* xn = x + (int64_t)n * D * H * W * xcs + ci0;
+#pragma unroll
+            for (int it = 0; it < NA; it++) {
+                int idx = threadIdx.x + it * BLK;
+                int half = idx & 1, vox = (idx >> 1) % WNV, cb = (idx >> 1) / WNV;
+                int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
+                int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
+                va[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (idx < CO_B * WNV * 2 && gz < D && gy < H && gx < W)
+                    va[it] = *reinterpret_cast<const bf16x8*>(dyn + ((gz * H + gy) * W + gx) * dycs + cb * 16 + half * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < NB; it++) {
+                int idx = threadIdx.x + it * BLK;
+                int half = idx & 1, vox = (idx >> 1) % WNH, cb = (idx >> 1) / WNH;
+                int ix = vox % WIX, tt = vox / WIX, iy = tt % WIY, iz = tt / WIY;
+                int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+                vb[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (idx < CI_B * WNH * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    vb[it] = *reinterpret_cast<const bf16x8*>(xn + ((gz * H + gy) * W + gx) * xcs + cb * 16 + half * 8);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NA; it++) {
+                int idx = threadIdx.x + it * BLK;
+                if (idx < CO_B * WNV * 2) *reinterpret_cast<bf16x8*>(dys + idx * 8) = va[it];
+            }
+#pragma unroll
+            for (int it = 0; it < NB; it++) {
+                int idx = threadIdx.x + it * BLK;
+                if (idx < CI_B * WNH * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = vb[it];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -489,7 +522,7 @@ inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     int groups = (Cout / (16 * c.cob)) * (Cin / (16 * c.cib));
     int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
     int blocks = c.cob * c.cib;
-    c.nt = blocks == 1 ? 27 : (blocks == 2 ? 9 : ((ntiles * groups >= 768) ? 9 : 3));
+    c.nt = blocks <= 2 ? 27 : 9;
     c.tg = 27 / c.nt;
     int64_t want = cdiv(512, (int64_t)groups * c.tg);
     if (want < 1) want = 1;
@@ -536,10 +569,9 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     const bf16* xp = (const bf16*)x; const bf16* dp = (const bf16*)dy;
     int rc;
     if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
-    else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
-    else if (c.cob == 1 && c.cib == 2) rc = launch_wgrad<1, 2, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
-    else if (c.nt == 9) rc = launch_wgrad<2, 2, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
-    else rc = launch_wgrad<2, 2, 3>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else if (c.cob == 1 && c.cib == 2) rc = launch_wgrad<1, 2, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else rc = launch_wgrad<2, 2, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
     MI3D_TRY(rc);
     slab_reduce2_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate);
     MI3D_LAUNCH_CHECK();
