@@ -212,14 +212,17 @@ __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restri
             (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
 }
 
-// one 64-thread block: sums[q] over blocks (double, fixed order), then loss + gradient coefficients
-__global__ void seg_loss_finalize_kernel(const double* __restrict__ part, int nblk, int N, int C, int64_t V, LossCfg cfg,
-                                         float* loss_out, float* coef) {
+// one 1024-thread block: wave w sums quantities w, w+16 over the block partials (lane-strided doubles + wave tree:
+// fixed order), then thread 0 computes the loss and the gradient coefficients
+__global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* __restrict__ part, int nblk, int N, int C,
+                                                                  int64_t V, LossCfg cfg, float* loss_out, float* coef) {
     __shared__ double sums[NQ];
-    if (threadIdx.x < NQ) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = wave; q < NQ; q += 16) {
         double s = 0.0;
-        for (int b = 0; b < nblk; b++) s += part[(int64_t)b * NQ + threadIdx.x];
-        sums[threadIdx.x] = s;
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * NQ + q];
+        s = wave_sum_d(s);
+        if (lane == 0) sums[q] = s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -330,22 +333,30 @@ __global__ __launch_bounds__(BLK) void seg_metrics_kernel(const float* __restric
         }
         nc += __popcll(__ballot(ok && best == t));
     }
+    // per-wave counts -> LDS -> one partial row per block (exact integers, no atomics)
+    __shared__ unsigned red[4][3 * MAXC + 1];
+    int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) {
-            if (c < C) {
-                if (ni[c]) atomicAdd(&counts[c], (unsigned long long)ni[c]);
-                if (np[c]) atomicAdd(&counts[MAXC + c], (unsigned long long)np[c]);
-                if (nt[c]) atomicAdd(&counts[2 * MAXC + c], (unsigned long long)nt[c]);
-            }
-        }
-        if (nc) atomicAdd(&counts[3 * MAXC], (unsigned long long)nc);
+        for (int c = 0; c < MAXC; c++) { red[wave][c] = ni[c]; red[wave][MAXC + c] = np[c]; red[wave][2 * MAXC + c] = nt[c]; }
+        red[wave][3 * MAXC] = nc;
     }
+    __syncthreads();
+    if (threadIdx.x < 3 * MAXC + 1)
+        counts[(int64_t)blockIdx.x * (3 * MAXC + 1) + threadIdx.x] =
+            (unsigned long long)red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // Q1: the reference's class loop is range(1, pred.size(1)) AFTER argmax -> bound = first spatial dim D
-__global__ void seg_metrics_finalize_kernel(const unsigned long long* counts, int N, int C, int D, int64_t V, float* out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void seg_metrics_finalize_kernel(const unsigned long long* part, int nblk, int N, int C, int D, int64_t V, float* out) {
+    __shared__ unsigned long long counts[3 * MAXC + 1];
+    if (threadIdx.x < 3 * MAXC + 1) {
+        unsigned long long s = 0;
+        for (int b = 0; b < nblk; b++) s += part[(int64_t)b * (3 * MAXC + 1) + threadIdx.x];
+        counts[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     float iou = 0.f, dice = 0.f;
     int valid = 0;
     for (int c = 1; c < D && c < C; c++) {
@@ -364,6 +375,7 @@ __global__ void seg_metrics_finalize_kernel(const unsigned long long* counts, in
     out[2] = (float)((double)counts[3 * MAXC] / ((double)N * (double)V));
 }
 
+constexpr int METRIC_BLOCKS = 256;
 inline int sgrid(int64_t total, int cap) {
     int64_t w = (total + BLK - 1) / BLK;
     return (int)(w < 1 ? 1 : (w > cap ? cap : w));
@@ -416,7 +428,7 @@ int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teache
     const float* tch = cfg.w_kd != 0.f ? teacher : nullptr;
     seg_loss_fwd_kernel<<<nblk, BLK, 0, s>>>(logits, labels, tch, N, C, V, 1.f / cfg.temp, (double*)ws);
     MI3D_LAUNCH_CHECK();
-    seg_loss_finalize_kernel<<<1, 64, 0, s>>>((const double*)ws, nblk, N, C, V, cfg, loss_out, coef);
+    seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, nblk, N, C, V, cfg, loss_out, coef);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -431,15 +443,15 @@ int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teache
     return 0;
 }
 
-size_t seg_metrics_ws_bytes(int C) { return (3 * MAXC + 1) * sizeof(unsigned long long); }
+size_t seg_metrics_ws_bytes(int C) { return (size_t)METRIC_BLOCKS * (3 * MAXC + 1) * sizeof(unsigned long long); }
 
 int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out, void* ws,
                 hipStream_t s) {
     MI3D_CHECK_ARG(C >= 1 && C <= MAXC, "seg_metrics: %d classes unsupported", C);
-    MI3D_HIP(hipMemsetAsync(ws, 0, seg_metrics_ws_bytes(C), s));
-    seg_metrics_kernel<<<sgrid((int64_t)N * V / 4, 1024), BLK, 0, s>>>(logits, labels, N, C, V, (unsigned long long*)ws);
+    int nblk = sgrid((int64_t)N * V / 8, METRIC_BLOCKS);
+    seg_metrics_kernel<<<nblk, BLK, 0, s>>>(logits, labels, N, C, V, (unsigned long long*)ws);
     MI3D_LAUNCH_CHECK();
-    seg_metrics_finalize_kernel<<<1, 64, 0, s>>>((const unsigned long long*)ws, N, C, D, V, out);
+    seg_metrics_finalize_kernel<<<1, 64, 0, s>>>((const unsigned long long*)ws, nblk, N, C, D, V, out);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

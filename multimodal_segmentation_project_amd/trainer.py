@@ -24,6 +24,7 @@ import torch.distributed as dist
 from . import _lib, engine
 from ._lib import LossCfg, call, ptr, ptr_table, stream_ptr
 from . import metrics as M
+from .dp import DataParallelComm, ParamArena
 
 
 def _loss_cfg(kind, kd_alpha=None, temperature=2.0):
@@ -35,37 +36,6 @@ def _loss_cfg(kind, kd_alpha=None, temperature=2.0):
         "ce": (1.0, 0, 0.0, 0.0, 0.0, 1e-6),
     }
     return M._cfg(*table.get(kind, table["combined"]))
-
-
-class ParamArena:
-    """Flat fp32 storage for parameters / gradients / AdamW moments; Parameters become views."""
-
-    def __init__(self, params, device):
-        self.params = list(params)
-        self.offsets, off = [], 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + 63) // 64 * 64          # 256-B aligned slots
-        self.numel = off
-        self.p = torch.zeros(off, dtype=torch.float32, device=device)
-        self.g = torch.zeros(off, dtype=torch.float32, device=device)
-        self.m = torch.zeros(off, dtype=torch.float32, device=device)
-        self.v = torch.zeros(off, dtype=torch.float32, device=device)
-        self.step = torch.zeros(1, dtype=torch.int64, device=device)
-        with torch.no_grad():
-            for p, o in zip(self.params, self.offsets):
-                view = self.p[o:o + p.numel()].view(p.shape)
-                view.copy_(p.data)
-                p.data = view
-                p.grad = self.g[o:o + p.numel()].view(p.shape)
-
-    def grad_ptrs(self):
-        return [self.g.data_ptr() + 4 * o for o in self.offsets]
-
-    def range_of(self, first, last):
-        """arena element range covering params[first:last]"""
-        end = self.offsets[last] if last < len(self.params) else self.numel
-        return self.offsets[first], end
 
 
 class TrainStep:
@@ -84,6 +54,8 @@ class TrainStep:
         self.device = next(model.parameters()).device
         _lib.require_cuda(next(model.parameters()), "TrainStep")
         self.arena = ParamArena(model.parameters(), self.device)
+        n_levels = len(model.encoder)
+        self.comm = DataParallelComm(self.arena, n_levels, process_group)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
         self.use_graph = bool(use_graph) and self.world == 1
         self._graph = None
@@ -94,13 +66,10 @@ class TrainStep:
 
     # ---- DDP construction semantics: rank 0's parameters and buffers win
     def broadcast_parameters(self):
-        dist.broadcast(self.arena.p, src=0, group=self.pg)
-        self.sync_buffers()
+        self.comm.broadcast_parameters(self.model.buffers())
 
     def sync_buffers(self):
-        if self.world > 1:
-            for b in self.model.buffers():
-                dist.broadcast(b, src=0, group=self.pg)
+        self.comm.sync_buffers(self.model.buffers())
 
     # ---- static state for one (shape, dtype)
     def _prepare(self, x):
@@ -137,18 +106,6 @@ class TrainStep:
             st["t_logits"] = torch.empty_like(st["logits"])
             st["t_ptab"] = ptr_table([p.data_ptr() for p in self.teacher.parameters()])
             st["t_btab"] = ptr_table([b.data_ptr() for b in self.teacher.buffers()])
-        # gradient buckets = contiguous arena ranges, keyed by the backward segment after which they are complete
-        npar = len(self.arena.params)
-        enc = lambda l: (8 * l, 8 * l + 8)                      # params-table range of encoder.l
-        bott = (8 * L, 8 * L + 8)
-        buckets = {L: self.arena.range_of(8 * (L + 1), npar),      # upconvs + decoder + final_conv
-                   L + 1: self.arena.range_of(*bott)}
-        if L > 1:
-            buckets[L + 2] = self.arena.range_of(*enc(L - 1))
-            buckets[2 * L + 1] = self.arena.range_of(0, 8 * (L - 1))
-        else:
-            buckets[2 * L + 1] = self.arena.range_of(0, 8)
-        st["buckets"] = buckets
         self._static = st
         self._graph = None
         return st
@@ -185,8 +142,8 @@ class TrainStep:
         for seg in range(nseg):
             call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop), ptr(st["dlogits"]),
                  None, 1.0, accumulate, seg, seg + 1, ptr(st["ws"]), st["ws_bytes"], s)
-            if do_comm and st["buckets"].get(seg) is not None:
-                self._allreduce_range(*st["buckets"][seg])
+            if do_comm and seg in self.comm.buckets:
+                self._allreduce_bucket(seg)
         if do_comm:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         # metrics on the device, one pass (replaces 3 argmaxes + 2(D-1) host-synchronising loops)
@@ -198,13 +155,13 @@ class TrainStep:
                  self.betas[1], self.eps, self.wd, 1.0, ptr(a.step), s)
         self.micro += 1
 
-    def _allreduce_range(self, lo, hi):
-        """Average arena.g[lo:hi] over ranks on the communication stream, ordered after the kernels enqueued so far."""
+    def _allreduce_bucket(self, seg):
+        """Average one finished gradient range over ranks on the communication stream, ordered after the kernels
+        enqueued so far; the compute stream keeps running the remaining backward segments."""
         cs = self.comm_stream
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
-            chunk = self.arena.g[lo:hi]
-            dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.pg)
+            self.comm.reduce_bucket(seg)
 
     def step(self, images, labels):
         """One micro-step on (images (N,Cin,D,H,W) float, labels (N,1,D,H,W) int64).  Returns a device float32[4]
@@ -226,8 +183,7 @@ class TrainStep:
             self.micro += 1
         else:
             self._enqueue(st)
-        if self.world > 1:
-            dist.all_reduce(st["metrics"], op=dist.ReduceOp.AVG, group=self.pg)     # SURVEY C4 fused
+        self.comm.average_(st["metrics"])     # the four scalar gathers fused into one 4-float all-reduce
         return st["metrics"]
 
     def load_batch(self, images, labels):
