@@ -156,7 +156,10 @@ int mi3d_maxpool2_backward(int dtype, const void* dp, int dpcs, const void* z, i
     return maxpool2_bwd(dtype, dp, dpcs, z, zcs, dskip, dskipcs, dz, dzcs, C, Geo{N, D, H, W}, (hipStream_t)stream);
 }
 size_t mi3d_upconv2_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W) {
-    return (upconv2_pack_floats(Cin, Cout) + upconv2_bwd_ws_floats(Cin, Cout, Geo{N, D, H, W})) * sizeof(float);
+    Geo g{N, D, H, W};
+    size_t wsf = upconv2_bwd_ws_floats(Cin, Cout, g);
+    if (upconv2_mfma_supported(Cin, Cout, 8, 8) && upconv2_mfma_bwd_ws_floats(Cin, Cout, g) > wsf) wsf = upconv2_mfma_bwd_ws_floats(Cin, Cout, g);
+    return (upconv2_pack_floats(Cin, Cout) + wsf) * sizeof(float);
 }
 int mi3d_upconv2_forward(int dtype, const void* x, int xcs, int Cin, const float* w, const float* bias, void* y, int ycs,
                          int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
@@ -164,6 +167,10 @@ int mi3d_upconv2_forward(int dtype, const void* x, int xcs, int Cin, const float
     MI3D_CHECK_ARG(workspace_bytes >= mi3d_upconv2_workspace_bytes(Cin, Cout, N, D, H, W), "mi3d_upconv2_forward: workspace too small");
     float* wf = (float*)workspace;
     float* wb = wf + (size_t)cdiv(Cout, 8) * Cin * 64;
+    if (dtype == MI3D_BF16 && upconv2_mfma_supported(Cin, Cout, xcs, ycs) && !getenv("MI3D_FORCE_DIRECT")) {
+        MI3D_TRY(upconv2_mfma_pack(w, Cin, Cout, workspace, (hipStream_t)stream));
+        return upconv2_mfma_fwd(x, xcs, Cin, workspace, bias, y, ycs, Cout, Geo{N, D, H, W}, (hipStream_t)stream);
+    }
     MI3D_TRY(upconv2_pack(w, Cin, Cout, wf, wb, (hipStream_t)stream));
     return upconv2_fwd(dtype, x, xcs, Cin, wf, bias, y, ycs, Cout, Geo{N, D, H, W}, (hipStream_t)stream);
 }
@@ -176,6 +183,11 @@ int mi3d_upconv2_backward(int dtype, const void* x, int xcs, int Cin, const floa
     float* wf = (float*)workspace;
     float* wb = wf + (size_t)cdiv(Cout, 8) * Cin * 64;
     float* slabs = (float*)workspace + upconv2_pack_floats(Cin, Cout);
+    if (dtype == MI3D_BF16 && upconv2_mfma_supported(Cin, Cout, xcs, gycs) && (!dx || dxcs % 4 == 0) && !getenv("MI3D_FORCE_DIRECT")) {
+        MI3D_TRY(upconv2_mfma_pack(w, Cin, Cout, workspace, (hipStream_t)stream));
+        return upconv2_mfma_bwd(x, xcs, Cin, gy, gycs, Cout, workspace, dx, dxcs, dW, db, accumulate, slabs,
+                                upconv2_mfma_bwd_ws_floats(Cin, Cout, g), g, (hipStream_t)stream);
+    }
     MI3D_TRY(upconv2_pack(w, Cin, Cout, wf, wb, (hipStream_t)stream));
     return upconv2_bwd(dtype, x, xcs, Cin, gy, gycs, Cout, wb, dx, dxcs, dW, db, accumulate, slabs,
                        upconv2_bwd_ws_floats(Cin, Cout, g), g, (hipStream_t)stream);

@@ -80,6 +80,16 @@ int upconv2_bwd(int dtype, const void* x, int xcs, int Cin, const void* gy, int 
                 const float* wp_bwd, void* dx, int dxcs, float* dW, float* db, int accumulate, float* ws,
                 size_t ws_floats, Geo g, hipStream_t s);
 
+// MFMA versions (bf16, Cin % 32 == 0, Cout % 16 == 0)                                   upconv_mfma.hip
+bool upconv2_mfma_supported(int Cin, int Cout, int xcs, int ycs);
+size_t upconv2_mfma_pack_elems(int Cin, int Cout);           // bf16 elements (fwd + bwd images)
+int upconv2_mfma_pack(const float* w, int Cin, int Cout, void* wp, hipStream_t s);
+int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
+                     Geo g, hipStream_t s);
+size_t upconv2_mfma_bwd_ws_floats(int Cin, int Cout, Geo g);
+int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, int Cout, const void* wp, void* dx,
+                     int dxcs, float* dW, float* db, int accumulate, float* ws, size_t ws_floats, Geo g, hipStream_t s);
+
 // ---- final 1x1x1 conv, losses, metrics ------------------------------------------------ head_loss.hip
 // Reference: nn.Conv3d(16,4,1) models/unet.py:62,87 ; utils/metrics.py:14-40,65-129,137-190.
 int conv1_fwd(int dtype, const void* z, int zcs, int Cin, const float* w, const float* bias, float* logits,

@@ -39,6 +39,7 @@ struct Plan {
     BlockP blk[2 * MAXL + 1];
     int nblk;
     size_t cat[MAXL], pool[MAXL], zb, zd[MAXL], upw[MAXL], xcl;
+    bool up_mfma[MAXL];
     size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sC;
     size_t bnws, wgws, statpart;
     size_t wgws_floats;
@@ -127,8 +128,12 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     for (int i = 0; i < p.L; i++) {
         int l = p.L - 1 - i;
         p.zd[i] = take((size_t)p.geo[l].M() * p.C[l] * p.esz);
-        p.upw[i] = take(upconv2_pack_floats(2 * p.C[l], p.C[l]) * sizeof(float));
-        size_t wf = upconv2_bwd_ws_floats(2 * p.C[l], p.C[l], p.geo[l + 1]);
+        p.up_mfma[i] = p.dt == MI3D_BF16 && upconv2_mfma_supported(2 * p.C[l], p.C[l], 2 * p.C[l], 2 * p.C[l]) &&
+                       !getenv("MI3D_FORCE_DIRECT");
+        p.upw[i] = take(p.up_mfma[i] ? upconv2_mfma_pack_elems(2 * p.C[l], p.C[l]) * 2
+                                     : upconv2_pack_floats(2 * p.C[l], p.C[l]) * sizeof(float));
+        size_t wf = p.up_mfma[i] ? upconv2_mfma_bwd_ws_floats(2 * p.C[l], p.C[l], p.geo[l + 1])
+                                 : upconv2_bwd_ws_floats(2 * p.C[l], p.C[l], p.geo[l + 1]);
         if (wf > wg_floats) wg_floats = wf;
     }
     p.xcl = d->in_channels > 1 ? take((size_t)p.geo[0].M() * d->in_channels * p.esz) : 0;
@@ -318,11 +323,17 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
         int l = L - 1 - i;
         float* wf = c.at<float>(p.upw[i]);
         float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
-        MI3D_TRY(upconv2_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], wf, wb, c.s));
         const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
         char* catl = c.at<char>(p.cat[l]);
-        MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + (size_t)p.C[l] * p.esz,
-                             2 * p.C[l], p.C[l], p.geo[l + 1], c.s));
+        if (p.up_mfma[i]) {
+            MI3D_TRY(upconv2_mfma_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i]), c.s));
+            MI3D_TRY(upconv2_mfma_fwd(uin, 2 * p.C[l], 2 * p.C[l], c.at(p.upw[i]), c.P(p.up_pidx(i) + 1),
+                                      catl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l], p.geo[l + 1], c.s));
+        } else {
+            MI3D_TRY(upconv2_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], wf, wb, c.s));
+            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + (size_t)p.C[l] * p.esz,
+                                 2 * p.C[l], p.C[l], p.geo[l + 1], c.s));
+        }
         MI3D_TRY(block_forward(c, L + 1 + i, x, buffers, drop_scales, training));
     }
     MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
@@ -357,9 +368,14 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
             float* wf = c.at<float>(p.upw[i]);
             float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
             char* gcatl = c.at<char>(p.gcat[l]);
-            MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gcatl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l], wb,
-                                 c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1), accumulate, wgws,
-                                 p.wgws_floats, p.geo[l + 1], c.s));
+            if (p.up_mfma[i])
+                MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gcatl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l],
+                                          c.at(p.upw[i]), c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1),
+                                          accumulate, wgws, p.wgws_floats, p.geo[l + 1], c.s));
+            else
+                MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gcatl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l], wb,
+                                     c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1), accumulate, wgws,
+                                     p.wgws_floats, p.geo[l + 1], c.s));
         } else if (seg == L + 1) {
             if (dgap)
                 MI3D_TRY(gap_bwd(p.dt, dgap, gap_scale, c.at(p.gz[L]), p.C[L], p.C[L], d->N, p.geo[L].V(), dlogits ? 1 : 0, c.s));

@@ -1,0 +1,327 @@
+// upconv_mfma.hip — ConvTranspose3d(k=2,s=2) on the matrix cores (bf16 in / fp32 acc), forward, input-gradient
+// and weight-gradient.  Reference: nn.ConvTranspose3d(2f,f,2,stride=2), models/unet.py:56-58,79.
+//
+// The op is a per-voxel GEMM  out[v][tap][co] = sum_ci x[v][ci] W[ci][co][tap]  + a 2x2x2 pixel shuffle:
+//   fwd      : D[co][voxel] = A(W^T: 16 co x 32 ci) * B(x: 32 ci x 16 voxels); the B fragment of a lane is 16 B of
+//              one voxel's channels straight from global memory (no LDS); each lane stores 4 channels (8 B) of one
+//              output voxel directly into the concat buffer slice.
+//   bwd data : D[ci][voxel] = A(W: 16 ci x 32 (tap,co)) * B(g gathered: 32 (tap,co) x 16 voxels), same structure.
+//   bwd wgt  : K = voxels is the strided index -> x and g tiles in LDS, fragments via ds_read_b64_tr_b16,
+//              persistent workgroups, cross-wave LDS reduce, deterministic slabs (same scheme as conv3 wgrad).
+#include "ops.h"
+
+namespace {
+constexpr int BLK = 256;
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const char* base, int byteoff) {
+    auto* p0 = (lds_bf16x4*)(base + byteoff);
+    auto* p1 = (lds_bf16x4*)(base + byteoff + 128);
+    bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p0);
+    bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p1);
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// wf[(((tap*COBN + cob)*KS + ks)*64 + lane)*8 + j] = W[32ks + 8G + j][cob*16 + (lane&15)][tap]
+// wb[((cib*S + s)*64 + lane)*8 + j]                = W[cib*16 + (lane&15)][co0 + j][tap],  (tap,co0) from kk0 = 32s + 8G
+__global__ void upconv_pack_mfma_kernel(const float* __restrict__ w, int Cin, int Cout, bf16* __restrict__ wf,
+                                        bf16* __restrict__ wb) {
+    int64_t n = (int64_t)Cin * Cout * 8;
+    int KS = Cin / 32, COBN = Cout / 16, S = Cout / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += (int64_t)gridDim.x * blockDim.x) {
+        bool bw = i >= n;
+        int64_t k = bw ? i - n : i;
+        int j = k & 7, lane = (k >> 3) & 63, G = lane >> 4;
+        int64_t r = k >> 9;
+        if (!bw) {
+            int ks = r % KS; r /= KS; int cob = r % COBN; int tap = r / COBN;
+            int ci = 32 * ks + 8 * G + j, co = cob * 16 + (lane & 15);
+            wf[k] = (bf16)w[((int64_t)ci * Cout + co) * 8 + tap];
+        } else {
+            int s = r % S; int cib = r / S;
+            int kk0 = 32 * s + 8 * G, tap = kk0 / Cout, co = kk0 % Cout + j, ci = cib * 16 + (lane & 15);
+            wb[k] = (bf16)w[((int64_t)ci * Cout + co) * 8 + tap];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int KS>
+__global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __restrict__ x, int xcs, const bf16* __restrict__ wf,
+                                                              const float* __restrict__ bias, bf16* __restrict__ y, int ycs,
+                                                              int Cout, int N, int D, int H, int W) {
+    int64_t M = (int64_t)N * D * H * W;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, vn = lane & 15, G = lane >> 4;
+    int COBN = Cout / 16;
+    int64_t ngroups = (M + 15) / 16;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+        int64_t v = grp * 16 + vn;
+        bool ok = v < M;
+        int64_t vc = ok ? v : M - 1;
+        bf16x8 Bf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) Bf[ks] = *reinterpret_cast<const bf16x8*>(x + vc * xcs + 32 * ks + 8 * G);
+        int w_ = (int)(vc % W); int64_t r = vc / W; int h_ = (int)(r % H); r /= H; int d_ = (int)(r % D); int n = (int)(r / D);
+#pragma unroll
+        for (int tap = 0; tap < 8; tap++) {
+            int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
+            bf16* yp = y + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * ycs + 4 * G;
+            for (int cob = 0; cob < COBN; cob++) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const bf16* wp = wf + (((int64_t)tap * COBN + cob) * KS) * 512 + lane * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) acc = mfma16(*reinterpret_cast<const bf16x8*>(wp + ks * 512), Bf[ks], acc);
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = (bf16)(acc[j] + (bias ? bias[cob * 16 + 4 * G + j] : 0.f));
+                if (ok) *reinterpret_cast<bf16x4*>(yp + cob * 16) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward data
+template <int S>   // S = 8*Cout/32 K-steps
+__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* __restrict__ g, int gcs, int Cout,
+                                                                   const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
+                                                                   int Cin, int N, int D, int H, int W) {
+    int64_t M = (int64_t)N * D * H * W;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, vn = lane & 15, G = lane >> 4;
+    int CIBN = Cin / 16;
+    int64_t ngroups = (M + 15) / 16;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+        int64_t v = grp * 16 + vn;
+        bool ok = v < M;
+        int64_t vc = ok ? v : M - 1;
+        int w_ = (int)(vc % W); int64_t r = vc / W; int h_ = (int)(r % H); r /= H; int d_ = (int)(r % D); int n = (int)(r / D);
+        bf16x8 Bf[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            int kk0 = 32 * s + 8 * G, tap = kk0 / Cout, co0 = kk0 % Cout;
+            int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
+            Bf[s] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0);
+        }
+        for (int cib = 0; cib < CIBN; cib++) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const bf16* wp = wb + ((int64_t)cib * S) * 512 + lane * 8;
+#pragma unroll
+            for (int s = 0; s < S; s++) acc = mfma16(*reinterpret_cast<const bf16x8*>(wp + s * 512), Bf[s], acc);
+            bf16x4 o = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
+            if (ok) *reinterpret_cast<bf16x4*>(dx + v * dxcs + cib * 16 + 4 * G) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- backward weight
+constexpr int UV = 128;    // input voxels per LDS tile = 4 K-steps, one per wave
+template <typename Emit>
+__device__ __forceinline__ void reduce_waves32(f32x4 (&acc)[32], float* red, int wave, int lane, Emit emit) {
+#pragma unroll
+    for (int base = 0; base < 32; base += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(red + ((j * 4 + wave) * 64 + lane) * 4) = acc[base + j];
+        __syncthreads();
+        f32x4 s = *reinterpret_cast<f32x4*>(red + ((wave * 4 + 0) * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+            f32x4 t = *reinterpret_cast<f32x4*>(red + ((wave * 4 + w) * 64 + lane) * 4);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        emit(base + wave, s);
+    }
+}
+
+// workgroup = 2 ci-blocks x 2 co-blocks x 8 taps = 32 accumulator tiles; x tile [2][UV][16], g tile [2][8][UV][16]
+__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+                                                                     const bf16* __restrict__ g, int gcs, int Cout, int N,
+                                                                     int D, int H, int W, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    bf16* xs = reinterpret_cast<bf16*>(lds_raw);            // [2][UV][16]
+    bf16* gs = xs + 2 * UV * 16;                            // [2][8][UV][16]
+    const char* xsb = reinterpret_cast<const char*>(xs);
+    const char* gsb = reinterpret_cast<const char*>(gs);
+    int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    int cbn = (Cout - co0) >= 32 ? 2 : 1;                   // Cout = 16 -> one co block (second plane zero)
+    int lane = threadIdx.x & 63;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    int laneK = ((wave * 32 + 8 * G + q) * 16 + 4 * p) * 2;
+    f32x4 acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbs[2] = {0.f, 0.f};
+    int64_t M = (int64_t)N * D * H * W;
+    int64_t ntile = (M + UV - 1) / UV;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        constexpr int NA = (2 * UV * 2) / BLK, NB = (2 * 8 * UV * 2) / BLK;
+        bf16x8 va[NA], vb[NB];
+#pragma unroll
+        for (int it = 0; it < NA; it++) {
+            int idx = threadIdx.x + it * BLK;
+            int half = idx & 1, vox = (idx >> 1) % UV, cb = (idx >> 1) / UV;
+            int64_t v = tile * UV + vox;
+            va[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (v < M) va[it] = *reinterpret_cast<const bf16x8*>(x + v * xcs + ci0 + cb * 16 + half * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NB; it++) {
+            int idx = threadIdx.x + it * BLK;
+            int half = idx & 1, vox = (idx >> 1) % UV, r2 = (idx >> 1) / UV, tap = r2 % 8, cb = r2 / 8;
+            int64_t v = tile * UV + vox;
+            vb[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (v < M && cb < cbn) {
+                int w_ = (int)(v % W); int64_t r = v / W; int h_ = (int)(r % H); r /= H; int d_ = (int)(r % D); int n = (int)(r / D);
+                int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
+                vb[it] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0 + cb * 16 + half * 8);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NA; it++) *reinterpret_cast<bf16x8*>(xs + (threadIdx.x + it * BLK) * 8) = va[it];
+#pragma unroll
+        for (int it = 0; it < NB; it++) *reinterpret_cast<bf16x8*>(gs + (threadIdx.x + it * BLK) * 8) = vb[it];
+        __syncthreads();
+        bf16x8 A[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) A[a] = tr_frag(xsb, laneK + a * (UV * 32));
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (int tap = 0; tap < 8; tap++) {
+                bf16x8 B = tr_frag(gsb, laneK + (cb * 8 + tap) * (UV * 32));
+                if (blockIdx.y == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) dbs[cb] += (float)B[j];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; a++) acc[(a * 2 + cb) * 8 + tap] = mfma16(A[a], B, acc[(a * 2 + cb) * 8 + tap]);
+            }
+    }
+    int64_t nW = (int64_t)Cin * Cout * 8;
+    float* slab = slabs + (int64_t)blockIdx.x * (nW + Cout);
+    float* red = reinterpret_cast<float*>(lds_raw);
+    reduce_waves32(acc, red, wave, lane, [&](int idx, f32x4 sum) {
+        int tap = idx % 8, cb = (idx / 8) % 2, a = idx / 16;
+        if (cb < cbn) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int ci = ci0 + a * 16 + 4 * G + r, co = co0 + cb * 16 + (lane & 15);
+                slab[((int64_t)ci * Cout + co) * 8 + tap] = sum[r];
+            }
+        }
+    });
+    if (blockIdx.y == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+            float sv = dbs[cb];
+            sv += __shfl_xor(sv, 16, 64);
+            sv += __shfl_xor(sv, 32, 64);
+            if (lane < 16) red[(cb * 4 + wave) * 16 + lane] = sv;
+        }
+        __syncthreads();
+        if (threadIdx.x < cbn * 16) {
+            int cb = threadIdx.x / 16, c = threadIdx.x % 16;
+            slab[nW + co0 + threadIdx.x] = (red[(cb * 4 + 0) * 16 + c] + red[(cb * 4 + 1) * 16 + c]) +
+                                           (red[(cb * 4 + 2) * 16 + c] + red[(cb * 4 + 3) * 16 + c]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLK) void slab_reduce3_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
+                                                           int64_t nW, float* __restrict__ dW, float* __restrict__ db,
+                                                           int accumulate) {
+    __shared__ float red[8][32];
+    int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    int64_t i = (int64_t)blockIdx.x * 32 + e;
+    float s = 0.f;
+    if (i < slab_sz)
+        for (int b = sg; b < nslab; b += 8) s += slabs[(int64_t)b * slab_sz + i];
+    red[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && i < slab_sz) {
+        float tsum = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        if (i < nW) { if (dW) dW[i] = accumulate ? dW[i] + tsum : tsum; }
+        else if (db) { db[i - nW] = accumulate ? db[i - nW] + tsum : tsum; }
+    }
+}
+
+inline int upw_nsb(int Cin, int Cout, Geo g) {
+    int64_t ntile = (g.M() + UV - 1) / UV;
+    int groups = (Cin / 32) * cdiv(Cout, 32);
+    int64_t want = cdiv(512, groups);
+    return (int)(ntile < want ? ntile : want);
+}
+inline int wave_grid(int64_t M) {
+    int64_t w = (M + 63) / 64;
+    return (int)(w < 1 ? 1 : (w > 4096 ? 4096 : w));
+}
+}  // namespace
+
+bool upconv2_mfma_supported(int Cin, int Cout, int xcs, int ycs) {
+    int ks = Cin / 32, s = Cout / 4;
+    return Cin % 32 == 0 && Cout % 16 == 0 && xcs % 8 == 0 && ycs % 8 == 0 && (ks == 1 || ks == 2 || ks == 4 || ks == 8) &&
+           (s == 4 || s == 8 || s == 16 || s == 32);
+}
+size_t upconv2_mfma_pack_elems(int Cin, int Cout) { return 2 * (size_t)Cin * Cout * 8; }     // fwd + bwd images
+
+int upconv2_mfma_pack(const float* w, int Cin, int Cout, void* wp, hipStream_t s) {
+    int64_t n = (int64_t)upconv2_mfma_pack_elems(Cin, Cout);
+    bf16* wf = (bf16*)wp;
+    upconv_pack_mfma_kernel<<<cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256), 256, 0, s>>>(w, Cin, Cout, wf, wf + n / 2);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
+                     hipStream_t s) {
+    MI3D_CHECK_ARG(upconv2_mfma_supported(Cin, Cout, xcs, ycs), "upconv2_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
+    const bf16* xp = (const bf16*)x; const bf16* wf = (const bf16*)wp; bf16* yp = (bf16*)y;
+    int grid = wave_grid(g.M());
+#define UF(K) upconv_mfma_fwd_kernel<K><<<grid, BLK, 0, s>>>(xp, xcs, wf, bias, yp, ycs, Cout, g.N, g.D, g.H, g.W)
+    switch (Cin / 32) { case 1: UF(1); break; case 2: UF(2); break; case 4: UF(4); break; default: UF(8); break; }
+#undef UF
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t upconv2_mfma_bwd_ws_floats(int Cin, int Cout, Geo g) {
+    return (size_t)upw_nsb(Cin, Cout, g) * ((size_t)Cin * Cout * 8 + Cout);
+}
+
+int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, int Cout, const void* wp, void* dx, int dxcs,
+                     float* dW, float* db, int accumulate, float* ws, size_t ws_floats, Geo g, hipStream_t s) {
+    MI3D_CHECK_ARG(upconv2_mfma_supported(Cin, Cout, xcs, gycs), "upconv2_mfma_bwd: unsupported channels");
+    const bf16* xp = (const bf16*)x; const bf16* gp = (const bf16*)gy;
+    const bf16* wb = (const bf16*)wp + (size_t)Cin * Cout * 8;
+    if (dx) {
+        int grid = wave_grid(g.M());
+        bf16* dp = (bf16*)dx;
+#define UB(SS) upconv_mfma_bwd_data_kernel<SS><<<grid, BLK, 0, s>>>(gp, gycs, Cout, wb, dp, dxcs, Cin, g.N, g.D, g.H, g.W)
+        switch (Cout / 4) { case 4: UB(4); break; case 8: UB(8); break; case 16: UB(16); break; default: UB(32); break; }
+#undef UB
+        MI3D_LAUNCH_CHECK();
+    }
+    if (dW || db) {
+        int nsb = upw_nsb(Cin, Cout, g);
+        int64_t nW = (int64_t)Cin * Cout * 8, slab_sz = nW + Cout;
+        MI3D_CHECK_ARG(ws_floats >= (size_t)nsb * slab_sz, "upconv2_mfma_bwd: workspace too small");
+        static bool attr_set = false;
+        size_t lds = (size_t)(2 * UV + 16 * UV) * 32;
+        if (!attr_set) {
+            MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_mfma_bwd_weight_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        dim3 grid((unsigned)nsb, (unsigned)(Cin / 32), (unsigned)cdiv(Cout, 32));
+        upconv_mfma_bwd_weight_kernel<<<grid, BLK, lds, s>>>(xp, xcs, Cin, gp, gycs, Cout, g.N, g.D, g.H, g.W, ws);
+        MI3D_LAUNCH_CHECK();
+        slab_reduce3_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
+        MI3D_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -507,3 +507,39 @@ def test_conv3_first_layer_wgrad_mfma(orc, shape):
     _, rgw, rgb = orc.conv3d_bwd(x, wgt, gy)
     np.testing.assert_allclose(dW.cpu().numpy(), rgw, rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), rgb, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 3, 5, 7), (1, 64, 32, 4, 4, 6), (1, 256, 128, 2, 3, 2), (1, 128, 64, 3, 3, 3)])
+def test_upconv_mfma_vs_c_oracle(orc, shape):
+    """bf16 MFMA ConvTranspose3d(k2,s2): forward (strided write into a wider concat buffer), dx, dW, db."""
+    from multimodal_segmentation_project_amd import _lib
+    from multimodal_segmentation_project_amd._lib import call, ptr
+    n, cin, cout, d, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.integers(-8, 9, (n, cin, d, h, w)).astype(np.float32) / 8
+    wgt = rng.integers(-8, 9, (cin, cout, 2, 2, 2)).astype(np.float32) / 16
+    b = rng.integers(-8, 9, cout).astype(np.float32) / 4
+    gy = rng.integers(-8, 9, (n, cout, 2 * d, 2 * h, 2 * w)).astype(np.float32) / 8
+    xcl = t(x.transpose(0, 2, 3, 4, 1)).bfloat16()
+    wd, bd = t(wgt), t(b)
+    wsb = _lib.lib().mi3d_upconv2_workspace_bytes(cin, cout, n, d, h, w)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    # output goes to channels [cout, 2cout) of a [.., 2cout] buffer, like the plan's concat buffer
+    cat = torch.zeros((n, 2 * d, 2 * h, 2 * w, 2 * cout), device=DEV, dtype=torch.bfloat16)
+    call("mi3d_upconv2_forward", 1, ptr(xcl), cin, cin, ptr(wd), ptr(bd), cat.data_ptr() + 2 * cout, 2 * cout, cout,
+         n, d, h, w, ptr(ws), wsb, None)
+    ref = orc.convT2_fwd(x, wgt, b)
+    got = cat[..., cout:].float().cpu().numpy().transpose(0, 4, 1, 2, 3)
+    assert np.abs(got - ref).max() <= np.abs(ref).max() * 2 ** -8 + 1e-6
+    assert float(cat[..., :cout].abs().max()) == 0.0
+    gcat = torch.zeros_like(cat)
+    gcat[..., cout:] = t(gy.transpose(0, 2, 3, 4, 1)).bfloat16()
+    dx = torch.empty_like(xcl)
+    dW, db = torch.empty((cin, cout, 2, 2, 2), device=DEV), torch.empty(cout, device=DEV)
+    call("mi3d_upconv2_backward", 1, ptr(xcl), cin, cin, ptr(wd), gcat.data_ptr() + 2 * cout, 2 * cout, cout, ptr(dx), cin,
+         ptr(dW), ptr(db), 0, n, d, h, w, ptr(ws), wsb, None)
+    rgx, rgw, rgb = orc.convT2_bwd(x, wgt, gy)
+    gotx = dx.float().cpu().numpy().transpose(0, 4, 1, 2, 3)
+    assert np.abs(gotx - rgx).max() <= np.abs(rgx).max() * 2 ** -8 + 1e-6
+    np.testing.assert_allclose(dW.cpu().numpy(), rgw, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), rgb, rtol=1e-5, atol=1e-3)
