@@ -96,13 +96,13 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
     }
     const bf16* xn = x + (int64_t)n * D * H * W * xcs;
     int nchunk = Cin / 16;
-    for (int chunk = 0; chunk < nchunk; chunk++) {
-        bf16x8 sv[NIT];
+    bf16x8 sv[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + chunk * 16);
-        }
+    for (int it = 0; it < NIT; it++) {
+        sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it]);
+    }
+    for (int chunk = 0; chunk < nchunk; chunk++) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
@@ -110,6 +110,12 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
             if (idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = sv[it];
         }
         __syncthreads();
+        // async-stage split: the next chunk's global loads are in flight while this chunk's MFMAs run
+        if (chunk + 1 < nchunk) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++)
+                if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + (chunk + 1) * 16);
+        }
         const bf16* wc = wp + ((int64_t)chunk * 14 * nCobTotal + cobBase) * 512 + lane * 8;
 #pragma unroll
         for (int s = 0; s < 14; s++) {
@@ -281,7 +287,7 @@ __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NTILE], float* red, in
 }
 
 template <int CO_B, int CI_B, int NT>
-__global__ __launch_bounds__(BLK) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+__global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                                const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
                                                                int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
                                                                float* __restrict__ slabs) {
@@ -313,50 +319,55 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_mfma_kernel(const bf16* __res
     bool do_db = (tg == 0 && blockIdx.z == 0);
 
     int ntiles = N * tilesZ * tilesY * tilesX;
-    for (int tile = sb; tile < ntiles; tile += nsb) {
+    constexpr int NA = (CO_B * WNV * 2 + BLK - 1) / BLK, NB = (CI_B * WNH * 2 + BLK - 1) / BLK;
+    bf16x8 va[NA], vb[NB];
+    auto load_tile = [&](int tile) {
         int t = tile;
         int tx_ = t % tilesX; t /= tilesX;
         int ty_ = t % tilesY; t /= tilesY;
         int tz_ = t % tilesZ; int n = t / tilesZ;
         int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
-        {
-            constexpr int NA = (CO_B * WNV * 2 + BLK - 1) / BLK, NB = (CI_B * WNH * 2 + BLK - 1) / BLK;
-            bf16x8 va[NA], vb[NB];
-            const bf16* dyn = dy + (int64_t)n * D * H * W * dycs + co0;
-            const bf16* xn = x + (int64_t)n * D * H * W * xcs + ci0;
+        const bf16* dyn = dy + (int64_t)n * D * H * W * dycs + co0;
+        const bf16* xn = x + (int64_t)n * D * H * W * xcs + ci0;
 #pragma unroll
-            for (int it = 0; it < NA; it++) {
-                int idx = threadIdx.x + it * BLK;
-                int half = idx & 1, vox = (idx >> 1) % WNV, cb = (idx >> 1) / WNV;
-                int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
-                int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
-                va[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (idx < CO_B * WNV * 2 && gz < D && gy < H && gx < W)
-                    va[it] = *reinterpret_cast<const bf16x8*>(dyn + ((gz * H + gy) * W + gx) * dycs + cb * 16 + half * 8);
-            }
+        for (int it = 0; it < NA; it++) {
+            int idx = threadIdx.x + it * BLK;
+            int half = idx & 1, vox = (idx >> 1) % WNV, cb = (idx >> 1) / WNV;
+            int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
+            int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
+            va[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < CO_B * WNV * 2 && gz < D && gy < H && gx < W)
+                va[it] = *reinterpret_cast<const bf16x8*>(dyn + ((gz * H + gy) * W + gx) * dycs + cb * 16 + half * 8);
+        }
 #pragma unroll
-            for (int it = 0; it < NB; it++) {
-                int idx = threadIdx.x + it * BLK;
-                int half = idx & 1, vox = (idx >> 1) % WNH, cb = (idx >> 1) / WNH;
-                int ix = vox % WIX, tt = vox / WIX, iy = tt % WIY, iz = tt / WIY;
-                int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
-                vb[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (idx < CI_B * WNH * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    vb[it] = *reinterpret_cast<const bf16x8*>(xn + ((gz * H + gy) * W + gx) * xcs + cb * 16 + half * 8);
-            }
-            __syncthreads();
+        for (int it = 0; it < NB; it++) {
+            int idx = threadIdx.x + it * BLK;
+            int half = idx & 1, vox = (idx >> 1) % WNH, cb = (idx >> 1) / WNH;
+            int ix = vox % WIX, tt = vox / WIX, iy = tt % WIY, iz = tt / WIY;
+            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+            vb[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < CI_B * WNH * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                vb[it] = *reinterpret_cast<const bf16x8*>(xn + ((gz * H + gy) * W + gx) * xcs + cb * 16 + half * 8);
+        }
+    };
+    // prefetch the next tile into registers while computing (only where the register file has room for it)
+    constexpr bool PF = (NT * CO_B * CI_B > 27) && (NT * CO_B * CI_B + NA + NB) * 4 <= 250;
+    if (PF && sb < ntiles) load_tile(sb);
+    for (int tile = sb; tile < ntiles; tile += nsb) {
+        if (!PF) load_tile(tile);
+        __syncthreads();
 #pragma unroll
-            for (int it = 0; it < NA; it++) {
-                int idx = threadIdx.x + it * BLK;
-                if (idx < CO_B * WNV * 2) *reinterpret_cast<bf16x8*>(dys + idx * 8) = va[it];
-            }
+        for (int it = 0; it < NA; it++) {
+            int idx = threadIdx.x + it * BLK;
+            if (idx < CO_B * WNV * 2) *reinterpret_cast<bf16x8*>(dys + idx * 8) = va[it];
+        }
 #pragma unroll
-            for (int it = 0; it < NB; it++) {
-                int idx = threadIdx.x + it * BLK;
-                if (idx < CI_B * WNH * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = vb[it];
-            }
+        for (int it = 0; it < NB; it++) {
+            int idx = threadIdx.x + it * BLK;
+            if (idx < CI_B * WNH * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = vb[it];
         }
         __syncthreads();
+        if (PF && tile + nsb < ntiles) load_tile(tile + nsb);     // next tile's loads fly under this tile's MFMAs
 #pragma unroll
         for (int z = 0; z < WTZ; z++) {
             bf16x8 A[CO_B];
@@ -383,14 +394,14 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_mfma_kernel(const bf16* __res
     int64_t nW = (int64_t)Cout * Cin * 27;
     float* slab = slabs + (int64_t)sb * (nW + Cout);
     float* red = reinterpret_cast<float*>(lds_raw);
+    // slab layout = MFMA-native: tile (tap, co16-block, ci16-block) -> 64 lanes x 4 floats, so every store is a
+    // coalesced 1 KB wave write; slab_reduce_mfma_kernel un-permutes into torch's (Cout,Cin,3,3,3) once at the end
+    int COBN = Cout / 16, CIBN = Cin / 16;
     reduce_waves<NTILE>(acc, red, wave, lane, [&](int idx, f32x4 sum) {
         int b = idx % CI_B, a = (idx / CI_B) % CO_B, i = idx / (CI_B * CO_B);
         int tap = tg * NT + i;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int co = co0 + a * 16 + 4 * G + r, ci = ci0 + b * 16 + (lane & 15);
-            slab[((int64_t)co * Cin + ci) * 27 + tap] = sum[r];
-        }
+        int64_t tileIdx = ((int64_t)tap * COBN + (co0 / 16 + a)) * CIBN + (ci0 / 16 + b);
+        *reinterpret_cast<f32x4*>(slab + tileIdx * 256 + lane * 4) = sum;
     });
     if (do_db) {
         __syncthreads();
@@ -494,10 +505,12 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_c1_kernel(const float* __rest
         slab[nW + co0 + threadIdx.x] = (red[threadIdx.x] + red[16 + threadIdx.x]) + (red[32 + threadIdx.x] + red[48 + threadIdx.x]);
 }
 
-// fixed-order parallel slab sum: block = 32 elements x 8 slab groups
+// fixed-order parallel slab sum: block = 32 elements x 8 slab groups.  MFMA_LAYOUT: slab elements are in the
+// (tap, co-block, ci-block, lane, reg) order written above and are un-permuted to torch's (Cout, Cin, 27) here.
+template <bool MFMA_LAYOUT>
 __global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
                                                            int64_t nW, float* __restrict__ dW, float* __restrict__ db,
-                                                           int accumulate) {
+                                                           int accumulate, int Cin, int Cout) {
     __shared__ float red[8][32];
     int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
     int64_t i = (int64_t)blockIdx.x * 32 + e;
@@ -508,8 +521,17 @@ __global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restri
     __syncthreads();
     if (sg == 0 && i < slab_sz) {
         float tsum = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
-        if (i < nW) { if (dW) dW[i] = accumulate ? dW[i] + tsum : tsum; }
-        else if (db) { db[i - nW] = accumulate ? db[i - nW] + tsum : tsum; }
+        if (i < nW) {
+            int64_t o = i;
+            if (MFMA_LAYOUT) {
+                int r = i & 3, lane = (i >> 2) & 63; int64_t t = i >> 8;
+                int CIBN = Cin / 16, COBN = Cout / 16;
+                int cib = t % CIBN; t /= CIBN; int cob = t % COBN; int tap = t / COBN;
+                int co = cob * 16 + 4 * (lane >> 4) + r, ci = cib * 16 + (lane & 15);
+                o = ((int64_t)co * Cin + ci) * 27 + tap;
+            }
+            if (dW) dW[o] = accumulate ? dW[o] + tsum : tsum;
+        } else if (db) { db[i - nW] = accumulate ? db[i - nW] + tsum : tsum; }
     }
 }
 
@@ -524,7 +546,7 @@ inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     int blocks = c.cob * c.cib;
     c.nt = blocks <= 2 ? 27 : 9;
     c.tg = 27 / c.nt;
-    int64_t want = cdiv(512, (int64_t)groups * c.tg);
+    int64_t want = 512 / ((int64_t)groups * c.tg);     // floor: total workgroups <= 2 per CU, no ragged third round
     if (want < 1) want = 1;
     c.nsb = (int)(ntiles < want ? ntiles : want);
     return c;
@@ -573,7 +595,7 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     else if (c.cob == 1 && c.cib == 2) rc = launch_wgrad<1, 2, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
     else rc = launch_wgrad<2, 2, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
     MI3D_TRY(rc);
-    slab_reduce2_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate);
+    slab_reduce2_kernel<true><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -589,7 +611,7 @@ int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo 
     conv3_wgrad_c1_kernel<<<grid, BLK, 0, s>>>(x, (const bf16*)dy, dycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ), cdiv(g.H, WTY),
                                                cdiv(g.W, WTX), ws);
     MI3D_LAUNCH_CHECK();
-    slab_reduce2_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
+    slab_reduce2_kernel<false><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, 1, Cout);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

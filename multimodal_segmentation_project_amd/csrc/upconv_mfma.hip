@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __rest
         for (int tap = 0; tap < 8; tap++) {
             int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
             bf16* yp = y + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * ycs + 4 * G;
-            for (int cob = 0; cob < COBN; cob++) {
+            for (int cob = blockIdx.y; cob < COBN; cob += gridDim.y) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const bf16* wp = wf + (((int64_t)tap * COBN + cob) * KS) * 512 + lane * 8;
 #pragma unroll
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* _
             int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
             Bf[s] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0);
         }
-        for (int cib = 0; cib < CIBN; cib++) {
+        for (int cib = blockIdx.y; cib < CIBN; cib += gridDim.y) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const bf16* wp = wb + ((int64_t)cib * S) * 512 + lane * 8;
 #pragma unroll
@@ -281,7 +281,10 @@ int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const floa
                      hipStream_t s) {
     MI3D_CHECK_ARG(upconv2_mfma_supported(Cin, Cout, xcs, ycs), "upconv2_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
     const bf16* xp = (const bf16*)x; const bf16* wf = (const bf16*)wp; bf16* yp = (bf16*)y;
-    int grid = wave_grid(g.M());
+    int gx = wave_grid(g.M());
+    int gy = 1;
+    while (gx * gy < 512 && gy < Cout / 16) gy *= 2;      // few voxels (deep levels): parallelise over channel blocks
+    dim3 grid((unsigned)gx, (unsigned)gy);
 #define UF(K) upconv_mfma_fwd_kernel<K><<<grid, BLK, 0, s>>>(xp, xcs, wf, bias, yp, ycs, Cout, g.N, g.D, g.H, g.W)
     switch (Cin / 32) { case 1: UF(1); break; case 2: UF(2); break; case 4: UF(4); break; default: UF(8); break; }
 #undef UF
@@ -299,7 +302,10 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
     const bf16* xp = (const bf16*)x; const bf16* gp = (const bf16*)gy;
     const bf16* wb = (const bf16*)wp + (size_t)Cin * Cout * 8;
     if (dx) {
-        int grid = wave_grid(g.M());
+        int gx = wave_grid(g.M());
+        int gy = 1;
+        while (gx * gy < 512 && gy < Cin / 16) gy *= 2;
+        dim3 grid((unsigned)gx, (unsigned)gy);
         bf16* dp = (bf16*)dx;
 #define UB(SS) upconv_mfma_bwd_data_kernel<SS><<<grid, BLK, 0, s>>>(gp, gycs, Cout, wb, dp, dxcs, Cin, g.N, g.D, g.H, g.W)
         switch (Cout / 4) { case 4: UB(4); break; case 8: UB(8); break; case 16: UB(16); break; default: UB(32); break; }
