@@ -47,7 +47,10 @@ __global__ void pack_mfma_kernel(const float* __restrict__ w, int Cin, int Cout,
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS>
+// SPLITK: blockIdx.z owns a contiguous range of 16-channel input chunks and writes fp32 partial outputs
+// part[kz][voxel][CoutTotal] (no bias / statistics); splitk_finish_kernel sums them.  Used for the deep levels
+// where the spatial tile count alone cannot fill 256 CUs (M = N*V is small, K = 27*Cin is large).
+template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK>
 __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                          const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                          bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
@@ -95,14 +98,19 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
         soff[it] = inb ? ((gz * H + gy) * W + gx) * xcs + half * 8 : -1;
     }
     const bf16* xn = x + (int64_t)n * D * H * W * xcs;
-    int nchunk = Cin / 16;
+    int nchunk = Cin / 16, chunk0 = 0;
+    if (SPLITK) {
+        int per = nchunk / gridDim.z;
+        chunk0 = blockIdx.z * per;
+        nchunk = chunk0 + per;
+    }
     bf16x8 sv[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it]);
+        if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + chunk0 * 16);
     }
-    for (int chunk = 0; chunk < nchunk; chunk++) {
+    for (int chunk = chunk0; chunk < nchunk; chunk++) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
@@ -136,6 +144,22 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
         }
     }
 
+    if constexpr (SPLITK) {
+        // fp32 partial tile: part[kz][voxel][CoutTotal], 4 channels (16 B) per lane
+        int64_t Mtot = (int64_t)(gridDim.x / (tilesZ * tilesY * tilesX)) * D * H * W;
+        float* pk = part + (int64_t)blockIdx.z * Mtot * CoutTotal;
+#pragma unroll
+        for (int r = 0; r < MB; r++) {
+            int bz = wave, byb = r / TXB, bxb = r % TXB;
+            int gz = z0 + bz, gy = y0 + byb * BY + vn / BX, gx = x0 + bxb * BX + vn % BX;
+            if (gz < D && gy < H && gx < W) {
+                float* pp = pk + ((((int64_t)n * D + gz) * H + gy) * W + gx) * CoutTotal + cobBase * 16 + g * 4;
+#pragma unroll
+                for (int c = 0; c < COB; c++) *reinterpret_cast<f32x4*>(pp + c * 16) = acc[r][c];
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias, bf16 store (4 channels = 8 B per lane), BN partial statistics of the rounded values
     float s1[COB][4], s2[COB][4];
 #pragma unroll
@@ -181,23 +205,56 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
     }
 }
 
-struct TileCfg { int tz, ty, tx; };
+// y[v][c] = bf16(bias[c] + sum_k part[k][v][c]); 8 channels per thread
+__global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int64_t M, int C,
+                                                            const float* __restrict__ bias, bf16* __restrict__ y, int ycs) {
+    int G8 = C / 8;
+    int64_t total = M * G8;
+    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+        int64_t v = idx / G8;
+        int c0 = (int)(idx - v * G8) * 8;
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = bias ? bias[c0 + j] : 0.f;
+        for (int k = 0; k < ksplit; k++) {
+            const float* p = part + ((int64_t)k * M + v) * C + c0;
+            f32x4 u = *reinterpret_cast<const f32x4*>(p), w = *reinterpret_cast<const f32x4*>(p + 4);
+            a[0] += u[0]; a[1] += u[1]; a[2] += u[2]; a[3] += u[3]; a[4] += w[0]; a[5] += w[1]; a[6] += w[2]; a[7] += w[3];
+        }
+        st8<bf16>(y + v * ycs + c0, a);
+    }
+}
 
 template <int TZ, int TYB, int TXB, int BX, int COB>
 int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bias, bf16* y, int ycs, int Cout, Geo g,
-               float* part, hipStream_t s) {
+               float* part, int ksplit, float* skws, hipStream_t s) {
     constexpr int TY = TYB * (16 / BX), TX = TXB * BX;
     int tz = cdiv(g.D, TZ), ty = cdiv(g.H, TY), tx = cdiv(g.W, TX);
-    dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)));
-    if (part)
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part);
+    dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)), (unsigned)ksplit);
+    if (ksplit > 1) {
+        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, nullptr, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, skws);
+        MI3D_LAUNCH_CHECK();
+        int64_t tot = g.M() * (Cout / 8);
+        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ksplit, g.M(), Cout, bias, y, ycs);
+    } else if (part)
+        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part);
     else
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr);
+        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
 
 inline bool big_geo(Geo g) { return g.W >= 32 && g.H >= 16; }
+
+// K-split factor: only for the small-geometry configuration, when the (tile x cout-group) grid is below ~one
+// workgroup per CU; power of two dividing the chunk count
+inline int pick_ksplit(int Cin, int Cout, Geo g) {
+    if (big_geo(g)) return 1;
+    int64_t wgs = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 8) * (Cout / (Cout % 32 == 0 ? 32 : 16));
+    int nchunk = Cin / 16, k = 1;
+    while (wgs * k < 256 && k * 2 <= nchunk && nchunk % (k * 2) == 0 && k < 16) k *= 2;
+    return k;
+}
 
 }  // namespace
 
@@ -214,25 +271,36 @@ int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dg
     return 0;
 }
 
-// number of per-workgroup statistic partials the forward launch writes (0 if it would not run with stats)
+// number of per-workgroup statistic partials the forward launch writes
 int conv3_mfma_stat_blocks(Geo g) {
     if (big_geo(g)) return g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
     return g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 8);
 }
 
+// fp32 scratch the K-split path needs for this layer (0 = single-pass kernel)
+size_t conv3_mfma_splitk_floats(int Cin, int Cout, Geo g) {
+    int k = pick_ksplit(Cin, Cout, g);
+    return k > 1 ? (size_t)k * g.M() * Cout : 0;
+}
+// true when a forward launch with `part` fills the BN partials itself (single-pass kernel)
+bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g) { return pick_ksplit(Cin, Cout, g) == 1; }
+
 // y = conv(x, wp) (+ bias); part != NULL -> also write BN partial sums [nblk][2][Cout] of the rounded outputs
+// (only when conv3_mfma_fuses_stats); skws = K-split scratch (conv3_mfma_splitk_floats) or NULL to force single pass
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
-                   float* part, hipStream_t s) {
+                   float* part, float* skws, hipStream_t s) {
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, ycs), "conv3_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
     MI3D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, "conv3_mfma_fwd: misaligned tensors");
     const bf16* xp = (const bf16*)x; const bf16* w = (const bf16*)wp; bf16* yp = (bf16*)y;
     bool two = Cout % 32 == 0;
+    int ks = skws ? pick_ksplit(Cin, Cout, g) : 1;
+    if (ks > 1) MI3D_CHECK_ARG(ycs % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv3_mfma_fwd: split-K needs 16-B aligned output rows");
     if (big_geo(g)) {
-        if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, s);
-        return launch_cfg<4, 8, 1, 16, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, s);
+        if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s);
+        return launch_cfg<4, 8, 1, 16, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s);
     }
-    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, s);
-    return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, s);
+    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s);
+    return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s);
 }
 
 // =================================================================================================== wgrad

@@ -31,8 +31,10 @@ size_t conv3_mfma_pack_elems(int Cin, int Cout);             // bf16 elements of
 int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, hipStream_t s);
 int conv3_mfma_stat_blocks(Geo g);                           // partials written when `part` != NULL
 // dgrad = same call with the dgrad pack and (Cin,Cout) swapped, bias NULL, part NULL
+size_t conv3_mfma_splitk_floats(int Cin, int Cout, Geo g);    // K-split scratch for deep (small-M) layers, 0 = none
+bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g);        // false -> caller runs bn_train_stats afterwards
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
-                   Geo g, float* part, hipStream_t s);
+                   Geo g, float* part, float* skws, hipStream_t s);
 
 size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,

@@ -41,7 +41,7 @@ struct Plan {
     size_t cat[MAXL], pool[MAXL], zb, zd[MAXL], upw[MAXL], xcl;
     bool up_mfma[MAXL];
     size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sC;
-    size_t bnws, wgws, statpart;
+    size_t bnws, wgws, statpart, skws;
     size_t wgws_floats;
     size_t total;
     int up_pidx(int i) const { return 8 * (L + 1) + 2 * i; }
@@ -77,7 +77,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     int64_t drop_off = 0;
-    size_t wg_floats = 0, maxCM = 0, statpart_floats = 1;
+    size_t wg_floats = 0, maxCM = 0, statpart_floats = 1, skws_floats = 1;
     int maxC = 1;
     p.nblk = 2 * p.L + 1;
     for (int b = 0; b < p.nblk; b++) {
@@ -100,6 +100,9 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
                 H.wpd = take(conv3_mfma_pack_elems(H.Cin, H.Cout) * 2);
                 size_t sp = (size_t)conv3_mfma_stat_blocks(g) * 2 * cout;
                 if (sp > statpart_floats) statpart_floats = sp;
+                size_t sk = conv3_mfma_splitk_floats(H.Cin, H.Cout, g), sk2 = conv3_mfma_splitk_floats(H.Cout, H.Cin, g);
+                if (sk > skws_floats) skws_floats = sk;
+                if (sk2 > skws_floats) skws_floats = sk2;
             } else {
                 H.wpf = take(conv3_direct_pack_floats(H.Cin, H.Cout) * sizeof(float));
                 H.wpd = take(conv3_direct_pack_floats(H.Cout, H.Cin) * sizeof(float));
@@ -143,6 +146,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     p.sC = take(maxCM * p.esz);
     p.bnws = take(bn_ws_floats(maxC) * sizeof(float));
     p.statpart = take(statpart_floats * sizeof(float));
+    p.skws = take(skws_floats * sizeof(float));
     p.wgws_floats = wg_floats;
     p.wgws = take(wg_floats * sizeof(float));
     p.total = off;
@@ -195,8 +199,8 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         if (H.mfma) {
             MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), c.s));
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
-                                    training ? c.at<float>(p.statpart) : nullptr, c.s));
-            fused_stats = training;
+                                    training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s));
+            fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
         } else {
             MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), c.at<float>(H.wpd), c.s));
             MI3D_TRY(conv3_direct_fwd(idt, p.dt, in, ics, H.Cin, c.at<float>(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout,
@@ -254,7 +258,8 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         int dxs = h == 1 ? H.Cin : dxcs;
         if (dx) {
             if (H.mfma)
-                MI3D_TRY(conv3_mfma_fwd(c.at(p.sB), H.Cout, H.Cout, c.at(H.wpd), nullptr, dx, dxs, H.Cin, g, nullptr, c.s));
+                MI3D_TRY(conv3_mfma_fwd(c.at(p.sB), H.Cout, H.Cout, c.at(H.wpd), nullptr, dx, dxs, H.Cin, g, nullptr,
+                                        (dxs % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s));
             else
                 MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, c.at(p.sB), H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
         }
