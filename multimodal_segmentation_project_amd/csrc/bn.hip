@@ -112,19 +112,22 @@ __global__ void bn_eval_stats_kernel(int C, const float* gamma, const float* bet
     stat[3 * C + c] = (float)((double)beta[c] - (double)rm[c] * (double)gamma[c] * inv);
 }
 
+// grid stride (gridDim*BLK) is a multiple of G = C/VEC (launcher guarantees it), so a thread's channel group is
+// fixed: per-channel coefficients are loaded into registers ONCE instead of per element
 template <typename T, int VEC>
 __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, int ycs, int C, int64_t M, int64_t V,
                                                        const float* __restrict__ stat, const float* __restrict__ drop,
                                                        T* __restrict__ z, int zcs) {
     int G = C / VEC;
-    int64_t total = M * G;
-    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
-        int64_t row = idx / G;
-        int g = (int)(idx - row * G);
+    int64_t gtid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    int g = (int)(gtid % G);
+    int64_t row = gtid / G, rstep = ((int64_t)gridDim.x * BLK) / G;
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i]; }
+    for (; row < M; row += rstep) {
         float v[VEC], o[VEC];
         ldv<T, VEC>(y + row * ycs + g * VEC, v);
-        const float* a = stat + 2 * C + g * VEC;
-        const float* b = stat + 3 * C + g * VEC;
         const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
@@ -192,29 +195,38 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
     }
 }
 
+// dy = g*(dyh - c1 - xhat*c2) rewritten per channel as  dy = g*dyh + A*y + B  with
+//   A = -g*c2*invstd,  B = g*(c2*invstd*mean - c1);  coefficients live in registers (fixed channel group per thread)
 template <typename T, int VEC>
 __global__ __launch_bounds__(BLK) void bn_bwd_apply_kernel(const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
                                                            int ycs, int C, int64_t M, int64_t V,
                                                            const float* __restrict__ stat, const float* __restrict__ coef,
                                                            const float* __restrict__ drop, T* __restrict__ dy, int dycs) {
     int G = C / VEC;
-    int64_t total = M * G;
-    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
-        int64_t row = idx / G;
-        int g = (int)(idx - row * G);
+    int64_t gtid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    int g = (int)(gtid % G);
+    int64_t row = gtid / G, rstep = ((int64_t)gridDim.x * BLK) / G;
+    float a[VEC], b[VEC], gg[VEC], A[VEC], B[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+        int c = g * VEC + i;
+        float mean = stat[c], inv = stat[C + c];
+        a[i] = stat[2 * C + c]; b[i] = stat[3 * C + c];
+        gg[i] = coef[2 * C + c];
+        float k = gg[i] * coef[C + c] * inv;
+        A[i] = -k;
+        B[i] = k * mean - gg[i] * coef[c];
+    }
+    for (; row < M; row += rstep) {
         float yv[VEC], gv[VEC], o[VEC];
         ldv<T, VEC>(y + row * ycs + g * VEC, yv);
         ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
         const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
-        int c0 = g * VEC;
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
-            float a = stat[2 * C + c0 + i], b = stat[3 * C + c0 + i];
-            float pre = fmaf(yv[i], a, b);
+            float pre = fmaf(yv[i], a[i], b[i]);
             float m = pre > 0.f ? (dr ? dr[i] : 1.f) : 0.f;
-            float dyh = gv[i] * m;
-            float xh = (yv[i] - stat[c0 + i]) * stat[C + c0 + i];
-            o[i] = coef[2 * C + c0 + i] * (dyh - coef[c0 + i] - xh * coef[C + c0 + i]);
+            o[i] = fmaf(gg[i] * m, gv[i], fmaf(A[i], yv[i], B[i]));
         }
         stv<T, VEC>(dy + row * dycs + g * VEC, o);
     }
@@ -230,10 +242,15 @@ inline int reduce_grid(int64_t M, int R) {
     if (want < 1) want = 1;
     return (int)(want > MAXBLK ? MAXBLK : want);
 }
-inline int stream_grid(int64_t total) {
+// grid for the streaming kernels: gridDim*BLK must be a multiple of G (fixed channel group per thread)
+inline int stream_grid(int64_t total, int G) {
     int64_t want = (total + BLK - 1) / BLK;
     if (want < 1) want = 1;
-    return (int)(want > 256 * 8 ? 256 * 8 : want);
+    if (want > 256 * 8) want = 256 * 8;
+    int m = 1;
+    while ((m * BLK) % G != 0) m++;            // G = 5 -> m = 5, powers of two -> m = 1
+    want = (want + m - 1) / m * m;
+    return (int)want;
 }
 
 }  // namespace
@@ -279,9 +296,9 @@ int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int6
     MI3D_CHECK_ARG(C >= 1 && M >= 1, "bn_apply: bad shape");
     DISPATCH_T(dtype, T, {
         if (vec8_ok(C, ycs, zcs, y, z, sizeof(T)))
-            bn_apply_kernel<T, 8><<<stream_grid(M * (C / 8)), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
+            bn_apply_kernel<T, 8><<<stream_grid(M * (C / 8), C / 8), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
         else
-            bn_apply_kernel<T, 1><<<stream_grid(M * C), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
+            bn_apply_kernel<T, 1><<<stream_grid(M * C, C), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
         MI3D_LAUNCH_CHECK();
     });
     return 0;
@@ -304,9 +321,9 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
         bn_bwd_finalize_kernel<<<C, 64, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);
         MI3D_LAUNCH_CHECK();
         if (v8)
-            bn_bwd_apply_kernel<T, 8><<<stream_grid(M * (C / 8)), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
+            bn_bwd_apply_kernel<T, 8><<<stream_grid(M * (C / 8), C / 8), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
         else
-            bn_bwd_apply_kernel<T, 1><<<stream_grid(M * C), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
+            bn_bwd_apply_kernel<T, 1><<<stream_grid(M * C, C), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
         MI3D_LAUNCH_CHECK();
     });
     return 0;

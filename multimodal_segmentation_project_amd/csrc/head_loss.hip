@@ -348,12 +348,15 @@ __global__ __launch_bounds__(BLK) void seg_metrics_kernel(const float* __restric
 }
 
 // Q1: the reference's class loop is range(1, pred.size(1)) AFTER argmax -> bound = first spatial dim D
-__global__ void seg_metrics_finalize_kernel(const unsigned long long* part, int nblk, int N, int C, int D, int64_t V, float* out) {
+__global__ __launch_bounds__(1024) void seg_metrics_finalize_kernel(const unsigned long long* part, int nblk, int N, int C,
+                                                                    int D, int64_t V, float* out) {
     __shared__ unsigned long long counts[3 * MAXC + 1];
-    if (threadIdx.x < 3 * MAXC + 1) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = wave; q < 3 * MAXC + 1; q += 16) {         // exact integer sums, wave-parallel
         unsigned long long s = 0;
-        for (int b = 0; b < nblk; b++) s += part[(int64_t)b * (3 * MAXC + 1) + threadIdx.x];
-        counts[threadIdx.x] = s;
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * (3 * MAXC + 1) + q];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) counts[q] = s;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -375,7 +378,7 @@ __global__ void seg_metrics_finalize_kernel(const unsigned long long* part, int 
     out[2] = (float)((double)counts[3 * MAXC] / ((double)N * (double)V));
 }
 
-constexpr int METRIC_BLOCKS = 256;
+constexpr int METRIC_BLOCKS = 1024;
 inline int sgrid(int64_t total, int cap) {
     int64_t w = (total + BLK - 1) / BLK;
     return (int)(w < 1 ? 1 : (w > cap ? cap : w));
@@ -451,7 +454,7 @@ int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D,
     int nblk = sgrid((int64_t)N * V / 8, METRIC_BLOCKS);
     seg_metrics_kernel<<<nblk, BLK, 0, s>>>(logits, labels, N, C, V, (unsigned long long*)ws);
     MI3D_LAUNCH_CHECK();
-    seg_metrics_finalize_kernel<<<1, 64, 0, s>>>((const unsigned long long*)ws, nblk, N, C, D, V, out);
+    seg_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const unsigned long long*)ws, nblk, N, C, D, V, out);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
