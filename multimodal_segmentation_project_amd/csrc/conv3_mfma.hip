@@ -110,6 +110,18 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
         sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + chunk0 * 16);
     }
+    // weight fragments stream through a register ring PD K-steps deep (L2-resident, 1 KB per wave-load): the load for
+    // K-step s+PD is issued while K-step s computes, and the ring keeps running across chunk boundaries
+    constexpr int PD = 7;      // must divide the 14 K-steps of a chunk so ring slots line up across chunks
+    static_assert(14 % PD == 0, "ring depth must divide the K-steps per chunk");
+    auto wptr = [&](int chunk, int s, int c) {
+        return reinterpret_cast<const bf16x8*>(wp + (((int64_t)chunk * 14 + s) * nCobTotal + cobBase + c) * 512 + lane * 8);
+    };
+    bf16x8 wf[PD][COB];
+#pragma unroll
+    for (int s = 0; s < PD; s++)
+#pragma unroll
+        for (int c = 0; c < COB; c++) wf[s][c] = *wptr(chunk0, s, c);
     for (int chunk = chunk0; chunk < nchunk; chunk++) {
         __syncthreads();
 #pragma unroll
@@ -124,12 +136,19 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
             for (int it = 0; it < NIT; it++)
                 if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + (chunk + 1) * 16);
         }
-        const bf16* wc = wp + ((int64_t)chunk * 14 * nCobTotal + cobBase) * 512 + lane * 8;
 #pragma unroll
         for (int s = 0; s < 14; s++) {
-            bf16x8 wf[COB];
+            bf16x8 wcur[COB];
 #pragma unroll
-            for (int c = 0; c < COB; c++) wf[c] = *reinterpret_cast<const bf16x8*>(wc + ((int64_t)s * nCobTotal + c) * 512);
+            for (int c = 0; c < COB; c++) wcur[c] = wf[s % PD][c];
+            // refill this ring slot with the fragment PD K-steps ahead (possibly in the next chunk)
+            if (s + PD < 14) {
+#pragma unroll
+                for (int c = 0; c < COB; c++) wf[s % PD][c] = *wptr(chunk, s + PD, c);
+            } else if (chunk + 1 < nchunk) {
+#pragma unroll
+                for (int c = 0; c < COB; c++) wf[s % PD][c] = *wptr(chunk + 1, s + PD - 14, c);
+            }
             int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
             int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IX + (t0 % 3)) * 32;
             int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IX + (t1 % 3)) * 32;
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
                 int rowOff = (((r / TXB) * BY) * IX + (r % TXB) * BX) * 32;     // compile-time after unrolling
                 bf16x8 xf = *reinterpret_cast<const bf16x8*>(xsb + toff + rowOff);
 #pragma unroll
-                for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wf[c], xf, acc[r][c]);
+                for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wcur[c], xf, acc[r][c]);
             }
         }
     }
