@@ -64,7 +64,13 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
     __shared__ __attribute__((aligned(16))) bf16 xs[NVOX * 16];
     __shared__ float red[4][COB][16][2];
 
-    int tile = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
+    // CONTIGUOUS run of tiles -> halo voxels shared by neighbouring tiles hit in the same L2 (bijective remap)
+    int tile;
+    {
+        int nwg = gridDim.x, bid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
     int tx_ = tile % tilesX; tile /= tilesX;
     int ty_ = tile % tilesY; tile /= tilesY;
     int tz_ = tile % tilesZ; int n = tile / tilesZ;
