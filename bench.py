@@ -97,8 +97,17 @@ def roofline_dominant(size, batch, dtype_code, iters=10):
     vox = n * d ** 3
     algo_bytes = vox * (cin + cout) * esz + cout * cin * 27 * 4
     achieved = algo_bytes / (ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed PMC passes of this same loop (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs of `bench.py --roofline-only`, corrected by tools/pmc_traffic.py); null if the file is absent
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "roofline_kernel_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(f"{size}^3xN{batch}_{'bf16' if dtype_code == 1 else 'fp32'}")
+        except Exception:   # noqa: BLE001
+            traffic = None
     return {"bound": "hbm", "kernel": "conv3 fwd 32->16 (decoder.3.conv0)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": ms,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "ms_per_launch": ms,
             "algorithmic_bytes_per_launch": algo_bytes}
 
 
@@ -114,6 +123,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3 --pmc passes)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +140,9 @@ def main():
     import multimodal_segmentation_project_amd as mi
     from multimodal_segmentation_project_amd.trainer import TrainStep
 
+    if a.roofline_only:
+        print(json.dumps(roofline_dominant(a.size, a.batch, 1 if a.dtype == "bf16" else 0, iters=a.steps)))
+        return
     torch.manual_seed(0)
     model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=a.dropout).to(dev).train()
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
