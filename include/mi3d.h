@@ -81,7 +81,12 @@ int mi3d_unet_num_segments(const mi3d_unet_desc* d);
 int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                        const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale,
                        int accumulate, int seg_begin, int seg_end, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       void* stream, void* aux_stream, void* const* events);
+/* aux_stream/events (both NULL = single stream): a second hipStream_t and 4 hipEvent_t handles (mi3d_event_create);
+ * weight-gradient kernels then run on aux_stream beside the data-gradient chain (they only share the dy tensor),
+ * forked/joined with the events so the call stays stream-ordered for the caller and hipGraph-capturable. */
+int mi3d_event_create(void** event_out);
+int mi3d_event_destroy(void* event);
 /* params-table index ranges whose gradients segment `seg` produces: ranges = {first0, last0, first1, last1}
  * (half-open; the second range is the segment's upconv for decoder segments, otherwise {-1,-1}) */
 int mi3d_unet_segment_params(const mi3d_unet_desc* d, int seg, int* ranges);

@@ -40,7 +40,9 @@ _SIGS = {
     "mi3d_unet_dropout_count": (i64, [_DP]),
     "mi3d_unet_segment_params": (i32, [_DP, i32, C.POINTER(C.c_int)]),
     "mi3d_unet_forward": (i32, [_DP, vp, vp, vp, vp, i32, vp, vp, vp, sz, vp]),
-    "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp]),
+    "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp]),
+    "mi3d_event_create": (i32, [C.POINTER(vp)]),
+    "mi3d_event_destroy": (i32, [vp]),
     "mi3d_seg_loss_workspace_bytes": (sz, [i32]),
     "mi3d_seg_loss_forward": (i32, [vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, vp]),
     "mi3d_seg_loss_backward": (i32, [vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, vp]),

@@ -201,6 +201,18 @@ int mi3d_ndhwc_to_ncdhw(int dtype, const void* src, int scs, float* dst, int C, 
     return ndhwc_to_ncdhw(dtype, src, scs, dst, C, N, V, (hipStream_t)stream);
 }
 
+int mi3d_event_create(void** event_out) {
+    MI3D_CHECK_ARG(event_out, "mi3d_event_create: null output");
+    hipEvent_t e;
+    MI3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event_out = (void*)e;
+    return 0;
+}
+int mi3d_event_destroy(void* event) {
+    if (event) MI3D_HIP(hipEventDestroy((hipEvent_t)event));
+    return 0;
+}
+
 // ---- hipGraph helpers ---------------------------------------------------------------------------
 int mi3d_graph_begin(void* stream) {
     MI3D_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));

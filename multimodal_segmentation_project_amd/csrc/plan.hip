@@ -40,8 +40,8 @@ struct Plan {
     int nblk;
     size_t cat[MAXL], pool[MAXL], zb, zd[MAXL], upw[MAXL], xcl;
     bool up_mfma[MAXL];
-    size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sC;
-    size_t bnws, wgws, statpart, skws;
+    size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sB2, sC;
+    size_t bnws, wgws, wgws2, statpart, skws;
     size_t wgws_floats;
     size_t total;
     int up_pidx(int i) const { return 8 * (L + 1) + 2 * i; }
@@ -143,12 +143,14 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     size_t c1 = conv1_bwd_ws_floats(p.C[0], d->out_channels);
     if (c1 > wg_floats) wg_floats = c1;
     p.sB = take(maxCM * p.esz);
+    p.sB2 = take(maxCM * p.esz);
     p.sC = take(maxCM * p.esz);
     p.bnws = take(bn_ws_floats(maxC) * sizeof(float));
     p.statpart = take(statpart_floats * sizeof(float));
     p.skws = take(skws_floats * sizeof(float));
     p.wgws_floats = wg_floats;
     p.wgws = take(wg_floats * sizeof(float));
+    p.wgws2 = take(wg_floats * sizeof(float));
     p.total = off;
     return 0;
 }
@@ -158,6 +160,11 @@ struct Ctx {
     char* ws;
     const void* const* params;
     hipStream_t s;
+    // optional second stream: weight gradients run beside the data-gradient chain (fork/join with events; works
+    // eagerly and inside a hipGraph capture).  ev = {fork0, fork1, done0, done1}
+    hipStream_t s2 = nullptr;
+    hipEvent_t* ev = nullptr;
+    mutable int seq = 0;
     template <typename T = void> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
     const float* P(int i) const { return reinterpret_cast<const float*>(params[i]); }
 };
@@ -232,36 +239,48 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
     Geo g = p.geo[B.level];
     const void* xin; int xcs, xdt;
     block_input(c, b, x, xin, xcs, xdt);
-    float* wgws = c.at<float>(p.wgws);
     auto G = [&](int i) { return grads ? (float*)grads[i] : nullptr; };
+    bool two = c.s2 != nullptr && c.ev != nullptr;
     for (int h = 1; h >= 0; h--) {
         const HalfP& H = B.h[h];
+        int k = c.seq++;
+        void* dyb = c.at((k & 1) ? p.sB2 : p.sB);            // dy ping-pong: the aux-stream wgrad may still read the other one
+        if (two && k >= 2) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + (k & 1)], 0));
         const void* dz = h == 1 ? dz2 : c.at(p.sC);
         int dcs = h == 1 ? dzcs : H.Cout;
         MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
-                        drop ? drop + H.drop_off : nullptr, c.at(p.sB), H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
+                        drop ? drop + H.drop_off : nullptr, dyb, H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
                         c.at<float>(p.bnws), c.s));
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
         if (G(H.pidx) || G(H.pidx + 1)) {
+            hipStream_t ws_ = c.s;
+            float* wgws = c.at<float>(p.wgws);
+            if (two) {
+                MI3D_HIP(hipEventRecord(c.ev[k & 1], c.s));
+                MI3D_HIP(hipStreamWaitEvent(c.s2, c.ev[k & 1], 0));
+                ws_ = c.s2;
+                wgws = c.at<float>(p.wgws2);
+            }
             if (H.mfma)
-                MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
-                                          wgws, p.wgws_floats, c.s));
+                MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
+                                          wgws, p.wgws_floats, ws_));
             else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT"))
-                MI3D_TRY(conv3_mfma_wgrad_c1((const float*)in, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
-                                             wgws, p.wgws_floats, c.s));
+                MI3D_TRY(conv3_mfma_wgrad_c1((const float*)in, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
+                                             wgws, p.wgws_floats, ws_));
             else
-                MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, c.at(p.sB), H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
-                                            accumulate, wgws, p.wgws_floats, c.s));
+                MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
+                                            accumulate, wgws, p.wgws_floats, ws_));
+            if (two) MI3D_HIP(hipEventRecord(c.ev[2 + (k & 1)], c.s2));
         }
         void* dx = h == 1 ? c.at(p.sC) : dxin;
         int dxs = h == 1 ? H.Cin : dxcs;
         if (dx) {
             if (H.mfma)
-                MI3D_TRY(conv3_mfma_fwd(c.at(p.sB), H.Cout, H.Cout, c.at(H.wpd), nullptr, dx, dxs, H.Cin, g, nullptr,
+                MI3D_TRY(conv3_mfma_fwd(dyb, H.Cout, H.Cout, c.at(H.wpd), nullptr, dx, dxs, H.Cin, g, nullptr,
                                         (dxs % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s));
             else
-                MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, c.at(p.sB), H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
+                MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, dyb, H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
         }
     }
     return 0;
@@ -348,7 +367,8 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
 
 int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                        const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale, int accumulate,
-                       int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream) {
+                       int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
+                       void* const* events) {
     Plan p;
     MI3D_TRY(build_plan(d, p));
     MI3D_CHECK_ARG(x && params && grads && workspace, "mi3d_unet_backward: null pointer");
@@ -357,6 +377,7 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
     int L = p.L, nseg = 2 * L + 2;
     MI3D_CHECK_ARG(seg_begin >= 0 && seg_end <= nseg && seg_begin <= seg_end, "bad segment range [%d,%d)", seg_begin, seg_end);
     Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
+    if (aux_stream && events) { c.s2 = (hipStream_t)aux_stream; c.ev = (hipEvent_t*)events; }
     float* wgws = c.at<float>(p.wgws);
     auto G = [&](int i) { return (float*)grads[i]; };
     for (int seg = seg_begin; seg < seg_end; seg++) {
@@ -392,6 +413,11 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
             void* dx = l > 0 ? c.at(p.gp[l - 1]) : nullptr;
             MI3D_TRY(block_backward(c, l, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], dx, l > 0 ? p.C[l - 1] : 0, accumulate));
         }
+    }
+    // join: everything the aux stream produced is ordered before whatever the caller enqueues next on `stream`
+    if (c.s2 && c.seq > 0) {
+        MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2], 0));
+        if (c.seq > 1) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[3], 0));
     }
     return 0;
 }

@@ -41,7 +41,7 @@ def _loss_cfg(kind, kd_alpha=None, temperature=2.0):
 class TrainStep:
     def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
                  grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
-                 compute_dtype=None, use_graph=False):
+                 compute_dtype=None, use_graph=False, two_stream=False):
         self.model = model
         self.teacher = kd_teacher
         self.cfg = _loss_cfg(loss, kd_alpha if kd_teacher is not None else None, kd_temperature)
@@ -57,6 +57,16 @@ class TrainStep:
         n_levels = len(model.encoder)
         self.comm = DataParallelComm(self.arena, n_levels, process_group)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        # second compute stream: weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
+        self.aux_stream = torch.cuda.Stream(device=self.device) if two_stream else None
+        self._events = None
+        if two_stream:
+            evs = []
+            for _ in range(4):
+                e = C.c_void_p()
+                call("mi3d_event_create", C.byref(e))
+                evs.append(e.value)
+            self._events = ptr_table(evs)
         self.use_graph = bool(use_graph) and self.world == 1
         self._graph = None
         self._static = None
@@ -141,7 +151,8 @@ class TrainStep:
         do_comm = self.world > 1 and boundary
         for seg in range(nseg):
             call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop), ptr(st["dlogits"]),
-                 None, 1.0, accumulate, seg, seg + 1, ptr(st["ws"]), st["ws_bytes"], s)
+                 None, 1.0, accumulate, seg, seg + 1, ptr(st["ws"]), st["ws_bytes"], s,
+                 self.aux_stream.cuda_stream if self.aux_stream is not None else None, self._events)
             if do_comm and seg in self.comm.buckets:
                 self._allreduce_bucket(seg)
         if do_comm:
