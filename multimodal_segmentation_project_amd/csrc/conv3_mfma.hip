@@ -17,6 +17,8 @@
 //
 // Bank behaviour (BX = 16): the 16 lanes ds_read_b128 services together read 16 distinct 16-B slots mod 256 B
 // (stride 32 B, the two channel halves interleaved) -> conflict-free without padding.
+#include <stdlib.h>
+
 #include "ops.h"
 
 namespace {
@@ -230,6 +232,198 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------ persistent variant
+// Full-resolution layers (16->16, 32->16, 16->32: 60 % of all conv FLOPs and most of the bytes).  Same math and tile
+// (4 x 8 x 16 voxels) as conv3_mfma_kernel, restructured around what the profile showed (instruction-issue bound,
+// ~1100 instructions per 112 MFMAs, most of it per-workgroup setup):
+//   * a workgroup is PERSISTENT and strides over tiles: the staging map (piece -> relative offset) and ALL weight
+//     fragments (NCH*14*COB x 16 B per lane, <= 112 VGPRs) are set up once and stay in registers;
+//   * interior tiles take a check-free staging path (one add per 16-B piece); only border tiles test coordinates;
+//   * the next tile's (or chunk's) global loads are issued before the MFMA loop of the current one (T14 split);
+//   * BatchNorm partial sums accumulate in registers across tiles -> ONE partial row per workgroup.
+template <int COB, int NCH, bool STATS>
+__global__ __launch_bounds__(BLK, (COB * NCH == 1) ? 2 : 1) void conv3_mfma_persist_kernel(const bf16* __restrict__ x, int xcs,
+                                                                    const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                                    bf16* __restrict__ y, int ycs, int D, int H, int W,
+                                                                    int tilesZ, int tilesY, int tilesX, int ntiles,
+                                                                    float* __restrict__ part) {
+    constexpr int TZ = 4, TY = 8, TX = 16, IZ = 6, IY = 10, IX = 18, MB = 8;
+    constexpr int NVOX = IZ * IY * IX, NIT = (NVOX * 2 + BLK - 1) / BLK;
+    constexpr int CoutTotal = COB * 16;
+    __shared__ __attribute__((aligned(16))) bf16 xs[NVOX * 16];
+    __shared__ float red[4][COB][16][2];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int vn = lane & 15, g = lane >> 4;
+    int laneOff = ((vn * 16 + (g & 1) * 8) * 2) + wave * (IY * IX * 32);
+    const char* xsb = reinterpret_cast<const char*>(xs);
+
+    // ---- once per workgroup: staging map and resident weights
+    int rel[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int idx = threadIdx.x + it * BLK;
+        int vox = idx >> 1, half = idx & 1;
+        int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+        rel[it] = ((iz * H + iy) * W + ix) * xcs + half * 8;
+    }
+    bool lastValid = threadIdx.x + (NIT - 1) * BLK < NVOX * 2;
+    bf16x8 wf[NCH][14][COB];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+        for (int s = 0; s < 14; s++)
+#pragma unroll
+            for (int c = 0; c < COB; c++)
+                wf[ch][s][c] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)ch * 14 + s) * COB + c) * 512 + lane * 8);
+    float bv[COB][4];
+#pragma unroll
+    for (int c = 0; c < COB; c++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) bv[c][j] = bias ? bias[c * 16 + g * 4 + j] : 0.f;
+    float s1[COB][4], s2[COB][4];
+#pragma unroll
+    for (int c = 0; c < COB; c++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) s1[c][j] = s2[c][j] = 0.f;
+
+    bf16x8 sv[NIT];
+    auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
+        int tx_ = tile % tilesX; tile /= tilesX;
+        int ty_ = tile % tilesY; tile /= tilesY;
+        int tz_ = tile % tilesZ; n = tile / tilesZ;
+        z0 = tz_ * TZ; y0 = ty_ * TY; x0 = tx_ * TX;
+    };
+    auto load_pieces = [&](int tile, int chunk) {
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+        // element offset of halo voxel (0,0,0) of this tile (may point before the volume for border tiles: only
+        // dereferenced where the coordinate test passes)
+        int64_t base = ((((int64_t)n * D + (z0 - 1)) * H + (y0 - 1)) * W + (x0 - 1)) * xcs + chunk * 16;
+        const bf16* xb = x + base;
+        bool interior = z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+        if (interior) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                if (it < NIT - 1 || lastValid) sv[it] = *reinterpret_cast<const bf16x8*>(xb + rel[it]);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                int idx = threadIdx.x + it * BLK;
+                int vox = idx >> 1;
+                int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+                int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+                bool inb = idx < NVOX * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (inb) sv[it] = *reinterpret_cast<const bf16x8*>(xb + rel[it]);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_pieces(tile, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc[MB][COB];
+#pragma unroll
+        for (int r = 0; r < MB; r++)
+#pragma unroll
+            for (int c = 0; c < COB; c++) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                int idx = threadIdx.x + it * BLK;
+                if (it < NIT - 1 || idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = sv[it];
+            }
+            __syncthreads();
+            if (ch + 1 < NCH) load_pieces(tile, ch + 1);
+            else if (tile + (int)gridDim.x < ntiles) load_pieces(tile + gridDim.x, 0);
+            // LDS fragment reads are software-pipelined one K-step (8 x ds_read_b128) ahead of the MFMAs that consume
+            // them: with only 2 waves per SIMD the ~150-cycle LDS latency is otherwise exposed on every MFMA pair
+            auto frag_off = [&](int s) {
+                int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
+                int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IX + (t0 % 3)) * 32;
+                int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IX + (t1 % 3)) * 32;
+                return laneOff + ((g >> 1) ? off1 : off0);
+            };
+            // pipeline granularity: FG M-blocks per sub-step (8 where the register file has room, 4 at 2 waves/SIMD)
+            constexpr int FG = (COB * NCH == 1) ? 4 : 8;
+            constexpr int NSUB = 14 * (MB / FG);
+            bf16x8 xf[2][FG];
+            {
+                int toff = frag_off(0);
+#pragma unroll
+                for (int r = 0; r < FG; r++) xf[0][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + r * (IX * 32));
+            }
+#pragma unroll
+            for (int u = 0; u < NSUB; u++) {
+                int s = u / (MB / FG), h = u % (MB / FG);
+                if (u + 1 < NSUB) {
+                    int s1 = (u + 1) / (MB / FG), h1 = (u + 1) % (MB / FG);
+                    int toff = frag_off(s1);
+#pragma unroll
+                    for (int r = 0; r < FG; r++)
+                        xf[(u + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + (h1 * FG + r) * (IX * 32));
+                }
+#pragma unroll
+                for (int r = 0; r < FG; r++)
+#pragma unroll
+                    for (int c = 0; c < COB; c++) acc[h * FG + r][c] = mfma16(wf[ch][s][c], xf[u & 1][r], acc[h * FG + r][c]);
+            }
+        }
+        // ---- epilogue of this tile
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+        int gz = z0 + wave, gx = x0 + vn;
+        bf16* yrow = y + ((((int64_t)n * D + gz) * H + y0) * W + gx) * ycs + g * 4;
+        bool okzx = gz < D && gx < W;
+#pragma unroll
+        for (int r = 0; r < MB; r++) {
+            bool ok = okzx && (y0 + r) < H;
+#pragma unroll
+            for (int c = 0; c < COB; c++) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    o[j] = (bf16)(acc[r][c][j] + bv[c][j]);
+                    if (STATS) { float q = ok ? (float)o[j] : 0.f; s1[c][j] += q; s2[c][j] = fmaf(q, q, s2[c][j]); }
+                }
+                if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs + c * 16) = o;
+            }
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int c = 0; c < COB; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float a = s1[c][j], b = s2[c][j];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (vn == 0) { red[wave][c][g * 4 + j][0] = a; red[wave][c][g * 4 + j][1] = b; }
+            }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < COB * 16 * 2; idx += BLK) {
+            int k = idx & 1, chn = idx >> 1;
+            int c = chn / 16, cc = chn % 16;
+            float v = (red[0][c][cc][k] + red[1][c][cc][k]) + (red[2][c][cc][k] + red[3][c][cc][k]);
+            part[((int64_t)blockIdx.x * 2 + k) * CoutTotal + chn] = v;
+        }
+    }
+}
+
+constexpr int PERSIST_WGS = 512;
+inline bool persist_ok(int Cin, int Cout, Geo g) {
+    return g.W >= 32 && g.H >= 16 && ((Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 16) || (Cin == 16 && Cout == 32)) &&
+           !getenv("MI3D_NO_PERSIST");
+}
+inline int persist_grid(int Cin, int Cout, Geo g) {
+    int64_t nt = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
+    int want = (Cin == 16 && Cout == 16) ? PERSIST_WGS : PERSIST_WGS / 2;      // 2 resident workgroups per CU, or 1
+    return (int)(nt < want ? nt : want);
+}
+
 // y[v][c] = bf16(bias[c] + sum_k part[k][v][c]); 8 channels per thread
 __global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int64_t M, int C,
                                                             const float* __restrict__ bias, bf16* __restrict__ y, int ycs) {
@@ -297,7 +491,8 @@ int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dg
 }
 
 // number of per-workgroup statistic partials the forward launch writes
-int conv3_mfma_stat_blocks(Geo g) {
+int conv3_mfma_stat_blocks(int Cin, int Cout, Geo g) {
+    if (persist_ok(Cin, Cout, g)) return persist_grid(Cin, Cout, g);
     if (big_geo(g)) return g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
     return g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 8);
 }
@@ -318,6 +513,20 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     MI3D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, "conv3_mfma_fwd: misaligned tensors");
     const bf16* xp = (const bf16*)x; const bf16* w = (const bf16*)wp; bf16* yp = (bf16*)y;
     bool two = Cout % 32 == 0;
+    if (persist_ok(Cin, Cout, g)) {
+        int tz = cdiv(g.D, 4), ty = cdiv(g.H, 8), tx = cdiv(g.W, 16), nt = g.N * tz * ty * tx, grid = persist_grid(Cin, Cout, g);
+#define PK(COB_, NCH_)                                                                                                         \
+        do {                                                                                                                   \
+            if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part); \
+            else conv3_mfma_persist_kernel<COB_, NCH_, false><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr); \
+        } while (0)
+        if (Cin == 16 && Cout == 16) PK(1, 1);
+        else if (Cin == 32) PK(1, 2);
+        else PK(2, 1);
+#undef PK
+        MI3D_LAUNCH_CHECK();
+        return 0;
+    }
     int ks = skws ? pick_ksplit(Cin, Cout, g) : 1;
     if (ks > 1) MI3D_CHECK_ARG(ycs % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv3_mfma_fwd: split-K needs 16-B aligned output rows");
     if (big_geo(g)) {

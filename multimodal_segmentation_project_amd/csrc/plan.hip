@@ -98,7 +98,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
             if (H.mfma) {
                 H.wpf = take(conv3_mfma_pack_elems(H.Cin, H.Cout) * 2);
                 H.wpd = take(conv3_mfma_pack_elems(H.Cin, H.Cout) * 2);
-                size_t sp = (size_t)conv3_mfma_stat_blocks(g) * 2 * cout;
+                size_t sp = (size_t)conv3_mfma_stat_blocks(H.Cin, H.Cout, g) * 2 * cout;
                 if (sp > statpart_floats) statpart_floats = sp;
                 size_t sk = conv3_mfma_splitk_floats(H.Cin, H.Cout, g), sk2 = conv3_mfma_splitk_floats(H.Cout, H.Cin, g);
                 if (sk > skws_floats) skws_floats = sk;
@@ -214,7 +214,7 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
                                       H.Cout, g, c.s));
         }
         if (fused_stats) {
-            MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), conv3_mfma_stat_blocks(g), H.Cout, g.M(), c.P(H.pidx + 2),
+            MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
                                        c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.s));
         } else if (training) {
             MI3D_TRY(bn_train_stats(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt,
