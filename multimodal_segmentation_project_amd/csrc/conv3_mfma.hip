@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
 //   * the next tile's (or chunk's) global loads are issued before the MFMA loop of the current one (T14 split);
 //   * BatchNorm partial sums accumulate in registers across tiles -> ONE partial row per workgroup.
 template <int COB, int NCH, bool STATS>
-__global__ __launch_bounds__(BLK, (COB * NCH == 1) ? 2 : 1) void conv3_mfma_persist_kernel(const bf16* __restrict__ x, int xcs,
+__global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* __restrict__ x, int xcs,
                                                                     const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                                     bf16* __restrict__ y, int ycs, int D, int H, int W,
                                                                     int tilesZ, int tilesY, int tilesX, int ntiles,
@@ -250,7 +250,12 @@ __global__ __launch_bounds__(BLK, (COB * NCH == 1) ? 2 : 1) void conv3_mfma_pers
     constexpr int TZ = 4, TY = 8, TX = 16, IZ = 6, IY = 10, IX = 18, MB = 8;
     constexpr int NVOX = IZ * IY * IX, NIT = (NVOX * 2 + BLK - 1) / BLK;
     constexpr int CoutTotal = COB * 16;
+    // weights: resident in registers when they are 56 VGPRs (16->16), otherwise resident in LDS (28 KB) so that two
+    // workgroups still fit per CU (registers AND LDS)
+    constexpr bool WLDS = COB * NCH > 1;
+    constexpr int NWF = NCH * 14 * COB;
     __shared__ __attribute__((aligned(16))) bf16 xs[NVOX * 16];
+    __shared__ __attribute__((aligned(16))) bf16 wl[WLDS ? NWF * 512 : 8];
     __shared__ float red[4][COB][16][2];
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int vn = lane & 15, g = lane >> 4;
@@ -267,14 +272,19 @@ __global__ __launch_bounds__(BLK, (COB * NCH == 1) ? 2 : 1) void conv3_mfma_pers
         rel[it] = ((iz * H + iy) * W + ix) * xcs + half * 8;
     }
     bool lastValid = threadIdx.x + (NIT - 1) * BLK < NVOX * 2;
-    bf16x8 wf[NCH][14][COB];
+    bf16x8 wf[WLDS ? 1 : NCH][WLDS ? 1 : 14][COB];
+    if constexpr (WLDS) {
+        for (int i = threadIdx.x; i < NWF * 64; i += BLK)
+            *reinterpret_cast<bf16x8*>(wl + i * 8) = *reinterpret_cast<const bf16x8*>(wp + (int64_t)i * 8);
+    } else {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++)
+        for (int ch = 0; ch < NCH; ch++)
 #pragma unroll
-        for (int s = 0; s < 14; s++)
+            for (int s = 0; s < 14; s++)
 #pragma unroll
-            for (int c = 0; c < COB; c++)
-                wf[ch][s][c] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)ch * 14 + s) * COB + c) * 512 + lane * 8);
+                for (int c = 0; c < COB; c++)
+                    wf[ch][s][c] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)ch * 14 + s) * COB + c) * 512 + lane * 8);
+    }
     float bv[COB][4];
 #pragma unroll
     for (int c = 0; c < COB; c++)
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(BLK, (COB * NCH == 1) ? 2 : 1) void conv3_mfma_pers
                 return laneOff + ((g >> 1) ? off1 : off0);
             };
             // pipeline granularity: FG M-blocks per sub-step (8 where the register file has room, 4 at 2 waves/SIMD)
-            constexpr int FG = (COB * NCH == 1) ? 4 : 8;
+            constexpr int FG = 4;
             constexpr int NSUB = 14 * (MB / FG);
             bf16x8 xf[2][FG];
             {
@@ -366,10 +376,16 @@ __global__ __launch_bounds__(BLK, (COB * NCH == 1) ? 2 : 1) void conv3_mfma_pers
                     for (int r = 0; r < FG; r++)
                         xf[(u + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + (h1 * FG + r) * (IX * 32));
                 }
+                bf16x8 wcur[COB];
+#pragma unroll
+                for (int c = 0; c < COB; c++) {
+                    if constexpr (WLDS) wcur[c] = *reinterpret_cast<const bf16x8*>(wl + ((ch * 14 + s) * COB + c) * 512 + lane * 8);
+                    else wcur[c] = wf[ch][s][c];
+                }
 #pragma unroll
                 for (int r = 0; r < FG; r++)
 #pragma unroll
-                    for (int c = 0; c < COB; c++) acc[h * FG + r][c] = mfma16(wf[ch][s][c], xf[u & 1][r], acc[h * FG + r][c]);
+                    for (int c = 0; c < COB; c++) acc[h * FG + r][c] = mfma16(wcur[c], xf[u & 1][r], acc[h * FG + r][c]);
             }
         }
         // ---- epilogue of this tile
@@ -420,7 +436,7 @@ inline bool persist_ok(int Cin, int Cout, Geo g) {
 }
 inline int persist_grid(int Cin, int Cout, Geo g) {
     int64_t nt = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
-    int want = (Cin == 16 && Cout == 16) ? PERSIST_WGS : PERSIST_WGS / 2;      // 2 resident workgroups per CU, or 1
+    int want = PERSIST_WGS;      // 2 resident workgroups per CU
     return (int)(nt < want ? nt : want);
 }
 
