@@ -698,15 +698,22 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
                 }
             }
             int boff = laneB + z * (WIY * WIX * 32);
+            // B fragments (tap, ci-block) stream through a PFD-deep register ring so that 2*PFD transposed LDS reads are
+            // in flight ahead of the MFMAs (the compiler alone keeps only 2 fragments ahead -> LDS latency exposed)
+            constexpr int NTB = NT * CI_B, PFD = 4;
+            auto bfrag = [&](int t) { return tr_frag(xsb, boff + tapOff[t / CI_B] + (t % CI_B) * (WNH * 32)); };
+            bf16x8 Bq[PFD];
 #pragma unroll
-            for (int i = 0; i < NT; i++)
+            for (int t = 0; t < PFD && t < NTB; t++) Bq[t] = bfrag(t);
 #pragma unroll
-                for (int b = 0; b < CI_B; b++) {
-                    bf16x8 B = tr_frag(xsb, boff + tapOff[i] + b * (WNH * 32));
+            for (int t = 0; t < NTB; t++) {
+                bf16x8 Bc = Bq[t % PFD];
+                if (t + PFD < NTB) Bq[t % PFD] = bfrag(t + PFD);
+                int i = t / CI_B, b = t % CI_B;
 #pragma unroll
-                    for (int a = 0; a < CO_B; a++)
-                        acc[(i * CO_B + a) * CI_B + b] = mfma16(A[a], B, acc[(i * CO_B + a) * CI_B + b]);
-                }
+                for (int a = 0; a < CO_B; a++)
+                    acc[(i * CO_B + a) * CI_B + b] = mfma16(A[a], Bc, acc[(i * CO_B + a) * CI_B + b]);
+            }
         }
     }
     int64_t nW = (int64_t)Cout * Cin * 27;

@@ -23,13 +23,21 @@ inline int sgrid(int64_t total, int cap = 2048) {
     return (int)(w < 1 ? 1 : (w > cap ? cap : w));
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz, int64_t nW,
-                                   float* __restrict__ dW, float* __restrict__ db, int accumulate) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab_sz; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int b = 0; b < nslab; b++) s += slabs[(int64_t)b * slab_sz + i];
-        if (i < nW) { if (dW) dW[i] = accumulate ? dW[i] + s : s; }
-        else if (db) { db[i - nW] = accumulate ? db[i - nW] + s : s; }
+// fixed-order parallel slab sum: block = 32 elements x 8 slab groups (each thread sums every 8th slab, then a tree)
+__global__ __launch_bounds__(BLK) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz, int64_t nW,
+                                                          float* __restrict__ dW, float* __restrict__ db, int accumulate) {
+    __shared__ float red[8][32];
+    int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    int64_t i = (int64_t)blockIdx.x * 32 + e;
+    float s = 0.f;
+    if (i < slab_sz)
+        for (int b = sg; b < nslab; b += 8) s += slabs[(int64_t)b * slab_sz + i];
+    red[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && i < slab_sz) {
+        float t = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        if (i < nW) { if (dW) dW[i] = accumulate ? dW[i] + t : t; }
+        else if (db) { db[i - nW] = accumulate ? db[i - nW] + t : t; }
     }
 }
 
@@ -197,7 +205,7 @@ __global__ void scale_add_kernel(float* dst, const float* src, int64_t n, float 
 
 int slab_reduce(const float* slabs, int nslab, int64_t slab_sz, int64_t nW, float* dW, float* db, int accumulate,
                 hipStream_t s) {
-    slab_reduce_kernel<<<sgrid(slab_sz), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
+    slab_reduce_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
