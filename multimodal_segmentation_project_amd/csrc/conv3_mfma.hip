@@ -144,30 +144,50 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
             for (int it = 0; it < NIT; it++)
                 if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + (chunk + 1) * 16);
         }
-#pragma unroll
-        for (int s = 0; s < 14; s++) {
-            bf16x8 wcur[COB];
-#pragma unroll
-            for (int c = 0; c < COB; c++) wcur[c] = wf[s % PD][c];
-            // refill this ring slot with the fragment PD K-steps ahead (possibly in the next chunk)
-            if (s + PD < 14) {
-#pragma unroll
-                for (int c = 0; c < COB; c++) wf[s % PD][c] = *wptr(chunk, s + PD, c);
-            } else if (chunk + 1 < nchunk) {
-#pragma unroll
-                for (int c = 0; c < COB; c++) wf[s % PD][c] = *wptr(chunk + 1, s + PD - 14, c);
-            }
+        // K loop: the weight ring advances once per K-step; LDS fragment reads are software-pipelined FG M-blocks
+        // (one sub-step) ahead of the MFMAs that consume them
+        constexpr int FG = MB < 4 ? MB : 4;
+        constexpr int SUBS = MB / FG, NSUB = 14 * SUBS;
+        auto frag_off = [&](int s) {
             int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
             int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IX + (t0 % 3)) * 32;
             int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IX + (t1 % 3)) * 32;
-            int toff = laneOff + ((g >> 1) ? off1 : off0);
+            return laneOff + ((g >> 1) ? off1 : off0);
+        };
+        auto row_off = [&](int r) { return (((r / TXB) * BY) * IX + (r % TXB) * BX) * 32; };
+        bf16x8 xf[2][FG];
+        {
+            int toff = frag_off(0);
 #pragma unroll
-            for (int r = 0; r < MB; r++) {
-                int rowOff = (((r / TXB) * BY) * IX + (r % TXB) * BX) * 32;     // compile-time after unrolling
-                bf16x8 xf = *reinterpret_cast<const bf16x8*>(xsb + toff + rowOff);
+            for (int r = 0; r < FG; r++) xf[0][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(r));
+        }
+        bf16x8 wcur[COB];
 #pragma unroll
-                for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wcur[c], xf, acc[r][c]);
+        for (int u = 0; u < NSUB; u++) {
+            int s = u / SUBS, h = u % SUBS;
+            if (h == 0) {
+#pragma unroll
+                for (int c = 0; c < COB; c++) wcur[c] = wf[s % PD][c];
+                // refill this ring slot with the fragment PD K-steps ahead (possibly in the next chunk)
+                if (s + PD < 14) {
+#pragma unroll
+                    for (int c = 0; c < COB; c++) wf[s % PD][c] = *wptr(chunk, s + PD, c);
+                } else if (chunk + 1 < nchunk) {
+#pragma unroll
+                    for (int c = 0; c < COB; c++) wf[s % PD][c] = *wptr(chunk + 1, s + PD - 14, c);
+                }
             }
+            if (u + 1 < NSUB) {
+                int s1 = (u + 1) / SUBS, h1 = (u + 1) % SUBS;
+                int toff = frag_off(s1);
+#pragma unroll
+                for (int r = 0; r < FG; r++)
+                    xf[(u + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(h1 * FG + r));
+            }
+#pragma unroll
+            for (int r = 0; r < FG; r++)
+#pragma unroll
+                for (int c = 0; c < COB; c++) acc[h * FG + r][c] = mfma16(wcur[c], xf[u & 1][r], acc[h * FG + r][c]);
         }
     }
 
