@@ -45,7 +45,11 @@ def cpu_baseline(size, batch, max_seconds=30.0):
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
     x, y = synth(batch, size, 1234)
-    cores = torch.get_num_threads()
+    try:
+        cores = len(os.sched_getaffinity(0))        # the cores this process may actually use on the GPU box
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     times = []
     t_all = time.time()
     for it in range(4):

@@ -317,10 +317,11 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
         for (int j = 0; j < 4; j++) s1[c][j] = s2[c][j] = 0.f;
 
     bf16x8 sv[NIT];
+    // tile order: z fastest (z-neighbours share 2 of 6 halo slices), then y, then x
     auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
-        int tx_ = tile % tilesX; tile /= tilesX;
+        int tz_ = tile % tilesZ; tile /= tilesZ;
         int ty_ = tile % tilesY; tile /= tilesY;
-        int tz_ = tile % tilesZ; n = tile / tilesZ;
+        int tx_ = tile % tilesX; n = tile / tilesX;
         z0 = tz_ * TZ; y0 = ty_ * TY; x0 = tx_ * TX;
     };
     auto load_pieces = [&](int tile, int chunk) {
@@ -350,7 +351,13 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
         }
     };
 
-    int tile = blockIdx.x;
+    // XCD-aware start: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch) -> give them ADJACENT tiles so
+    // the halo voxels neighbouring tiles share are served by that XCD's L2 instead of the fabric (bijective remap)
+    int tile;
+    {
+        int nwg = gridDim.x, bid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
     if (tile < ntiles) load_pieces(tile, 0);
     for (; tile < ntiles; tile += gridDim.x) {
         f32x4 acc[MB][COB];
