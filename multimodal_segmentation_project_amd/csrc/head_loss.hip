@@ -70,31 +70,31 @@ __global__ __launch_bounds__(BLK) void conv1_fwd_kernel(const T* __restrict__ z,
 
 // per block (blockIdx.y = 16-channel input block): dz[v][ci] = sum_co dl[co][v] w[co][ci];
 // slab[blockIdx.x] = { dW[co][ci] partial, db[co] partial }
-template <typename T, bool VEC>
+template <typename T, bool VEC, int NCO>
 __global__ __launch_bounds__(BLK) void conv1_bwd_kernel(const T* __restrict__ z, int zcs, int Cin, const float* __restrict__ w,
                                                         const float* __restrict__ dl, int Cout, T* __restrict__ dz, int dzcs,
                                                         int N, int64_t V, float* __restrict__ slabs) {
-    __shared__ float red[4][MAXC * CINB + MAXC];
+    __shared__ float red[4][NCO * CINB + NCO];
     int64_t M = (int64_t)N * V;
     int c0 = blockIdx.y * CINB;
     int nci = min(CINB, Cin - c0);
-    float aw[MAXC][CINB], ab[MAXC];
+    float aw[NCO][CINB], ab[NCO];
 #pragma unroll
-    for (int j = 0; j < MAXC; j++) {
+    for (int j = 0; j < NCO; j++) {
         ab[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < CINB; i++) aw[j][i] = 0.f;
     }
     for (int64_t m = (int64_t)blockIdx.x * BLK + threadIdx.x; m < M; m += (int64_t)gridDim.x * BLK) {
         int64_t n = m / V, v = m - n * V;
-        float g[MAXC], zv[CINB], o[CINB];
+        float g[NCO], zv[CINB], o[CINB];
 #pragma unroll
-        for (int j = 0; j < MAXC; j++) g[j] = j < Cout ? dl[((int64_t)n * Cout + j) * V + v] : 0.f;
+        for (int j = 0; j < NCO; j++) g[j] = j < Cout ? dl[((int64_t)n * Cout + j) * V + v] : 0.f;
         load_cin_block<T, VEC>(z + m * zcs + c0, nci, zv);
 #pragma unroll
         for (int i = 0; i < CINB; i++) o[i] = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXC; j++) {
+        for (int j = 0; j < NCO; j++) {
             if (j < Cout) {
                 ab[j] += g[j];
 #pragma unroll
@@ -119,25 +119,25 @@ __global__ __launch_bounds__(BLK) void conv1_bwd_kernel(const T* __restrict__ z,
     }
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < MAXC; j++) {
+    for (int j = 0; j < NCO; j++) {
 #pragma unroll
         for (int i = 0; i < CINB; i++) {
             float s = wave_sum(aw[j][i]);
             if (lane == 0) red[wave][j * CINB + i] = s;
         }
         float sb = wave_sum(ab[j]);
-        if (lane == 0) red[wave][MAXC * CINB + j] = sb;
+        if (lane == 0) red[wave][NCO * CINB + j] = sb;
     }
     __syncthreads();
     int64_t nW = (int64_t)Cout * Cin;
     float* slab = slabs + (int64_t)blockIdx.x * (nW + Cout);
-    for (int idx = threadIdx.x; idx < MAXC * CINB + MAXC; idx += BLK) {
+    for (int idx = threadIdx.x; idx < NCO * CINB + NCO; idx += BLK) {
         float s = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
-        if (idx < MAXC * CINB) {
+        if (idx < NCO * CINB) {
             int j = idx / CINB, i = idx - j * CINB;
             if (j < Cout && i < nci) slab[(int64_t)j * Cin + c0 + i] = s;
         } else {
-            int j = idx - MAXC * CINB;
+            int j = idx - NCO * CINB;
             if (j < Cout && blockIdx.y == 0) slab[nW + j] = s;
         }
     }
@@ -412,10 +412,10 @@ int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const 
     dim3 grid((unsigned)nblk, (unsigned)cdiv(Cin, CINB));
     DISPATCH_T(dtype, T, {
         bool vec = Cin % CINB == 0 && zcs % 8 == 0 && al16(z) && (!dz || (dzcs % 8 == 0 && al16(dz)));
-        if (vec)
-            conv1_bwd_kernel<T, true><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
-        else
-            conv1_bwd_kernel<T, false><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
+if (vec && Cout <= 4) conv1_bwd_kernel<T, true, 4><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
+        else if (vec) conv1_bwd_kernel<T, true, MAXC><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
+        else if (Cout <= 4) conv1_bwd_kernel<T, false, 4><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
+        else conv1_bwd_kernel<T, false, MAXC><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
         MI3D_LAUNCH_CHECK();
     });
     return slab_reduce(ws, nblk, nW + Cout, nW, dW, db, accumulate, s);

@@ -57,6 +57,14 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __rest
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, vn = lane & 15, G = lane >> 4;
     int COBN = Cout / 16;
     int64_t ngroups = (M + 15) / 16;
+    // KS == 1 and one 16-channel output block (the full-resolution upconv, 32 -> 16): the 8 tap fragments are loop
+    // invariant -> keep them in registers instead of re-loading 8 KB per 16 voxels
+    bool hoist = KS == 1 && COBN == 1;
+    bf16x8 wh[8];
+    if (hoist) {
+#pragma unroll
+        for (int tap = 0; tap < 8; tap++) wh[tap] = *reinterpret_cast<const bf16x8*>(wf + (int64_t)tap * 512 + lane * 8);
+    }
     for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
         int64_t v = grp * 16 + vn;
         bool ok = v < M;
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __rest
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const bf16* wp = wf + (((int64_t)tap * COBN + cob) * KS) * 512 + lane * 8;
 #pragma unroll
-                for (int ks = 0; ks < KS; ks++) acc = mfma16(*reinterpret_cast<const bf16x8*>(wp + ks * 512), Bf[ks], acc);
+                for (int ks = 0; ks < KS; ks++) acc = mfma16(hoist ? wh[tap] : *reinterpret_cast<const bf16x8*>(wp + ks * 512), Bf[ks], acc);
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j++) o[j] = (bf16)(acc[j] + (bias ? bias[cob * 16 + 4 * G + j] : 0.f));
