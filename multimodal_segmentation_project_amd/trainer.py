@@ -203,10 +203,25 @@ class TrainStep:
         st["y"].copy_(labels.reshape(st["y"].shape))
 
     def _capture(self, st):
+        """Capture one micro-step into a hipGraph.  A warm-up execution is needed first (lazy code-object loading must
+        not happen inside the capture); it runs on a snapshot of all mutable state, which is restored afterwards, so
+        capturing is invisible to the training trajectory."""
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._enqueue(st)          # warm-up outside capture (first-touch, lazy module load)
+            a = self.arena
+            snap = [t.clone() for t in (a.p, a.g, a.m, a.v, a.step)]
+            bufs = [b.clone() for b in self.model.buffers()]
+            rng = engine._rng_state(self.model, self.device).clone()
+            micro = self.micro
+            self._enqueue(st)
+            s.synchronize()
+            for t, c in zip((a.p, a.g, a.m, a.v, a.step), snap):
+                t.copy_(c)
+            for b, c in zip(self.model.buffers(), bufs):
+                b.copy_(c)
+            engine._rng_state(self.model, self.device).copy_(rng)
+            self.micro = micro
             s.synchronize()
             call("mi3d_graph_begin", s.cuda_stream)
             try:
@@ -215,8 +230,8 @@ class TrainStep:
                 g = C.c_void_p()
                 call("mi3d_graph_end", s.cuda_stream, C.byref(g))
             self._graph = g
+            self.micro = micro             # the captured enqueue did not execute
         torch.cuda.current_stream().wait_stream(s)
-        self.micro -= 1                # the captured enqueue did not execute
 
     @torch.no_grad()
     def evaluate(self, images, labels):
