@@ -892,7 +892,9 @@ struct WgCfg { int cob, cib, nt, tg, nsb; };
 inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     WgCfg c;
     c.cob = Cout % 32 == 0 ? 2 : 1;
-    c.cib = Cin % 32 == 0 ? 2 : 1;
+    // Cout = 16 (one co block): two passes of the lean <1,1,27> kernel (2 workgroups/CU, 108 accumulators) beat one
+    // <1,2,27> pass (216 accumulators, 85 KB LDS, 1 workgroup/CU) although dy is staged twice
+    c.cib = (Cin % 32 == 0 && Cout % 32 == 0) ? 2 : 1;
     int groups = (Cout / (16 * c.cob)) * (Cin / (16 * c.cib));
     int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
     int blocks = c.cob * c.cib;
