@@ -84,7 +84,7 @@ int mi3d_conv3_forward(int in_dtype, int out_dtype, const void* x, int xcs, int 
     float* wpd = wpf + conv3_direct_pack_floats(Cin, Cout);
     hipStream_t s = (hipStream_t)stream;
     if (use_mfma(in_dtype, out_dtype, Cin, Cout, xcs, ycs)) {       // bf16 implicit GEMM on the matrix cores
-        MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, s));
+        MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, Geo{N, D, H, W}, s));
         return conv3_mfma_fwd(x, xcs, Cin, wpf, bias, y, ycs, Cout, Geo{N, D, H, W}, nullptr, nullptr, s);
     }
     MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
@@ -101,7 +101,7 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
     float* slabs = wpd + conv3_direct_pack_floats(Cout, Cin);
     hipStream_t s = (hipStream_t)stream;
     if (dx && use_mfma(dy_dtype, dy_dtype, Cout, Cin, dycs, dxcs)) {
-        MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, s));
+        MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, g, s));
         MI3D_TRY(conv3_mfma_fwd(dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, nullptr, nullptr, s));
     } else {
         MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));

@@ -29,10 +29,25 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// K-step -> tap assignment.  mode 0 (natural): K-step s holds taps (2s, 2s+1).  mode 1 ("row reuse", persistent
+// full-resolution kernel): taps are paired so that consecutive K-steps read the SAME LDS rows shifted by dy, which
+// lets one fragment register serve up to three MFMAs (see conv3_mfma_persist_kernel):
+//   s = 4dz+dy (dy<3): ((dz,dy,0),(dz,dy,1))   s = 4dz+3: ((dz,0,2),(dz,1,2))   s=12: ((0,2,2),(1,2,2))   s=13: ((2,2,2),pad)
+MI3D_HD constexpr int ktap(int mode, int s, int h) {
+    if (mode == 0) return 2 * s + h;
+    if (s < 12) {
+        int dz = s / 4, k = s % 4;
+        return k < 3 ? dz * 9 + k * 3 + h : dz * 9 + h * 3 + 2;
+    }
+    if (s == 12) return h * 9 + 8;
+    return h == 0 ? 26 : 27;
+}
+
 // ------------------------------------------------------------------------------------------------ pack
 // wf[(((chunk*14 + s)*COB + cob)*64 + lane)*8 + j] = W[cob*16 + (lane&15)][chunk*16 + 8*(g&1) + j][2s + (g>>1)]
 // wd[(((chunk*14 + s)*CIB + cib)*64 + lane)*8 + j] = W[chunk*16 + 8*(g&1) + j][cib*16 + (lane&15)][26 - (2s + (g>>1))]
-__global__ void pack_mfma_kernel(const float* __restrict__ w, int Cin, int Cout, bf16* __restrict__ wf, bf16* __restrict__ wd) {
+__global__ void pack_mfma_kernel(const float* __restrict__ w, int Cin, int Cout, bf16* __restrict__ wf, bf16* __restrict__ wd,
+                                 int mode_f, int mode_d) {
     int64_t n = (int64_t)Cin * Cout * 28;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += (int64_t)gridDim.x * blockDim.x) {
         bool dg = i >= n;
@@ -40,7 +55,7 @@ __global__ void pack_mfma_kernel(const float* __restrict__ w, int Cin, int Cout,
         int j = k & 7; int lane = (k >> 3) & 63; int64_t r = k >> 9;
         int nob = (dg ? Cin : Cout) / 16;
         int ob = r % nob; r /= nob; int s = r % 14; int chunk = r / 14;
-        int g = lane >> 4, tap = 2 * s + (g >> 1);
+        int g = lane >> 4, tap = ktap(dg ? mode_d : mode_f, s, g >> 1);
         int o = ob * 16 + (lane & 15), ic = chunk * 16 + 8 * (g & 1) + j;
         float v = 0.f;
         if (tap < 27) v = dg ? w[((int64_t)ic * Cin + o) * 27 + (26 - tap)] : w[((int64_t)o * Cin + ic) * 27 + tap];
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
     constexpr int CoutTotal = COB * 16;
     // weights: resident in registers when they are 56 VGPRs (16->16), otherwise resident in LDS (28 KB) so that two
     // workgroups still fit per CU (registers AND LDS)
-    constexpr bool WLDS = COB * NCH > 1;
+    constexpr bool WLDS = true;      // registers go to the F/G row fragments; weights (14-28 KB) live in LDS
     constexpr int NWF = NCH * 14 * COB;
     __shared__ __attribute__((aligned(16))) bf16 xs[NVOX * 16];
     __shared__ __attribute__((aligned(16))) bf16 wl[WLDS ? NWF * 512 : 8];
@@ -376,43 +391,71 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
             __syncthreads();
             if (ch + 1 < NCH) load_pieces(tile, ch + 1);
             else if (tile + (int)gridDim.x < ntiles) load_pieces(tile + gridDim.x, 0);
-            // LDS fragment reads are software-pipelined one K-step (8 x ds_read_b128) ahead of the MFMAs that consume
-            // them: with only 2 waves per SIMD the ~150-cycle LDS latency is otherwise exposed on every MFMA pair
-            auto frag_off = [&](int s) {
-                int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
-                int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IX + (t0 % 3)) * 32;
-                int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IX + (t1 % 3)) * 32;
-                return laneOff + ((g >> 1) ? off1 : off0);
+            // K loop with LDS-row reuse (ktap mode 1).  For a fixed dz the three K-steps (dz,dy,dx0|dx1), dy = 0..2, of
+            // M-block row y read halo row y+dy: 10 row fragments F[0..9] feed 24 MFMAs (2.4x fewer ds_read_b128); the
+            // dx = 2 taps pair up over dy (G), the last two K-steps over dz.  70 instead of 112 LDS reads per chunk.
+            auto W_ = [&](int s, int c) -> bf16x8 {
+                if constexpr (WLDS) return *reinterpret_cast<const bf16x8*>(wl + ((ch * 14 + s) * COB + c) * 512 + lane * 8);
+                else return wf[ch][s][c];
             };
-            // pipeline granularity: FG M-blocks per sub-step (8 where the register file has room, 4 at 2 waves/SIMD)
-            constexpr int FG = 4;
-            constexpr int NSUB = 14 * (MB / FG);
-            bf16x8 xf[2][FG];
-            {
-                int toff = frag_off(0);
+            const int hx = (g >> 1) * 32;                       // lane half -> dx = 0 | 1
+            const int hy = (g >> 1) * (IX * 32) + 64;           // lane half -> dy = 0 | 1 at dx = 2
+            const int hz = (g >> 1) * (IY * IX * 32) + (2 * IX + 2) * 32;   // lane half -> dz = 0 | 1 at (dy,dx) = (2,2)
+            bf16x8 F[10], G[8];
 #pragma unroll
-                for (int r = 0; r < FG; r++) xf[0][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + r * (IX * 32));
+            for (int row = 0; row < 10; row++) F[row] = *reinterpret_cast<const bf16x8*>(xsb + laneOff + hx + row * (IX * 32));
+#pragma unroll
+            for (int dz = 0; dz < 3; dz++) {
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    G[r] = *reinterpret_cast<const bf16x8*>(xsb + laneOff + hy + (dz * IY + r) * (IX * 32));
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    bf16x8 wc_[COB];
+#pragma unroll
+                    for (int c = 0; c < COB; c++) wc_[c] = W_(dz * 4 + dy, c);
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wc_[c], F[r + dy], acc[r][c]);
+                }
+                // next group's row fragments may overwrite F now (MFMAs read their operands at issue)
+                if (dz < 2) {
+#pragma unroll
+                    for (int row = 0; row < 10; row++)
+                        F[row] = *reinterpret_cast<const bf16x8*>(xsb + laneOff + hx + ((dz + 1) * IY + row) * (IX * 32));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; r++) F[r] = *reinterpret_cast<const bf16x8*>(xsb + laneOff + hz + r * (IX * 32));
+                }
+                {
+                    bf16x8 wc_[COB];
+#pragma unroll
+                    for (int c = 0; c < COB; c++) wc_[c] = W_(dz * 4 + 3, c);
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wc_[c], G[r], acc[r][c]);
+                }
             }
+            // s = 12: ((0,2,2),(1,2,2)) fragments are in F[0..7]; s = 13: ((2,2,2), pad) -> G
 #pragma unroll
-            for (int u = 0; u < NSUB; u++) {
-                int s = u / (MB / FG), h = u % (MB / FG);
-                if (u + 1 < NSUB) {
-                    int s1 = (u + 1) / (MB / FG), h1 = (u + 1) % (MB / FG);
-                    int toff = frag_off(s1);
+            for (int r = 0; r < 8; r++)
+                G[r] = *reinterpret_cast<const bf16x8*>(xsb + laneOff + (2 * IY * IX + 2 * IX + 2) * 32 + r * (IX * 32));
+            {
+                bf16x8 wc_[COB];
 #pragma unroll
-                    for (int r = 0; r < FG; r++)
-                        xf[(u + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + (h1 * FG + r) * (IX * 32));
-                }
-                bf16x8 wcur[COB];
+                for (int c = 0; c < COB; c++) wc_[c] = W_(12, c);
 #pragma unroll
-                for (int c = 0; c < COB; c++) {
-                    if constexpr (WLDS) wcur[c] = *reinterpret_cast<const bf16x8*>(wl + ((ch * 14 + s) * COB + c) * 512 + lane * 8);
-                    else wcur[c] = wf[ch][s][c];
-                }
+                for (int r = 0; r < 8; r++)
 #pragma unroll
-                for (int r = 0; r < FG; r++)
+                    for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wc_[c], F[r], acc[r][c]);
 #pragma unroll
-                    for (int c = 0; c < COB; c++) acc[h * FG + r][c] = mfma16(wcur[c], xf[u & 1][r], acc[h * FG + r][c]);
+                for (int c = 0; c < COB; c++) wc_[c] = W_(13, c);
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wc_[c], G[r], acc[r][c]);
             }
         }
         // ---- epilogue of this tile
@@ -526,9 +569,13 @@ bool conv3_mfma_supported(int Cin, int Cout, int xcs, int ycs) {
 
 size_t conv3_mfma_pack_elems(int Cin, int Cout) { return (size_t)Cin * Cout * 28; }   // one operand (fwd or dgrad)
 
-int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, hipStream_t s) {
+// g = the geometry the packs will be used at: it decides (with the channel counts) whether the forward / dgrad launch
+// runs the persistent row-reuse kernel, whose K-step -> tap order differs (ktap mode 1)
+int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g, hipStream_t s) {
     int64_t n = 2 * (int64_t)conv3_mfma_pack_elems(Cin, Cout);
-    pack_mfma_kernel<<<cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256), 256, 0, s>>>(w, Cin, Cout, (bf16*)wp_fwd, (bf16*)wp_dgrad);
+    int mode_f = persist_ok(Cin, Cout, g) ? 1 : 0, mode_d = persist_ok(Cout, Cin, g) ? 1 : 0;
+    pack_mfma_kernel<<<cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256), 256, 0, s>>>(w, Cin, Cout, (bf16*)wp_fwd, (bf16*)wp_dgrad,
+                                                                             mode_f, mode_d);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -28,7 +28,7 @@ int conv3_direct_wgrad(int x_dtype, int dy_dtype, const void* x, int xcs, int Ci
 // ---- 3x3x3 convolution, MFMA implicit GEMM (bf16, Cin,Cout % 16 == 0) ------------------ conv3_mfma.hip
 bool conv3_mfma_supported(int Cin, int Cout, int xcs, int ycs);
 size_t conv3_mfma_pack_elems(int Cin, int Cout);             // bf16 elements of ONE packed operand
-int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, hipStream_t s);
+int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g, hipStream_t s);
 int conv3_mfma_stat_blocks(int Cin, int Cout, Geo g);                           // partials written when `part` != NULL
 // dgrad = same call with the dgrad pack and (Cin,Cout) swapped, bias NULL, part NULL
 size_t conv3_mfma_splitk_floats(int Cin, int Cout, Geo g);    // K-split scratch for deep (small-M) layers, 0 = none

@@ -204,7 +204,7 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
         bool fused_stats = false;
         if (H.mfma) {
-            MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), c.s));
+            MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
                                     training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s));
             fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
