@@ -46,9 +46,11 @@ def cpu_baseline(size, batch, max_seconds=30.0):
             v.requires_grad_(True)
     x, y = synth(batch, size, 1234)
     try:
-        cores = len(os.sched_getaffinity(0))        # the cores this process may actually use on the GPU box
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        avail = os.cpu_count() or 1
+    # a 1-GPU box exposes all host cores but grants a 16-core share (oversubscribing 256 threads ran 14x slower)
+    cores = min(avail, int(os.environ.get("MI3D_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
     times = []
     t_all = time.time()
