@@ -695,12 +695,10 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
     int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     int laneA = (((2 * wave + (G >> 1)) * WTX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
     int laneB = (((2 * wave + (G >> 1)) * WIX + 8 * (G & 1) + q) * 16 + 4 * p) * 2;
-    int tapOff[NT];
-#pragma unroll
-    for (int i = 0; i < NT; i++) {
-        int t = tg * NT + i;
-        tapOff[i] = (((t / 9) * WIY + ((t / 3) % 3)) * WIX + (t % 3)) * 32;
-    }
+    // taps of this workgroup: NT = 27 -> all; NT = 9 -> the nine (dz, dx) taps of ONE dy (= tap group), so that every
+    // workgroup still sees all three dz and can reuse an x fragment of halo slice zz for the output slices zz-dz
+    constexpr int NY = NT / 9;                  // dy values handled here (3 or 1)
+    static_assert(NT == 27 || NT == 9, "tap grouping");
     constexpr int NTILE = NT * CO_B * CI_B;
     f32x4 acc[NTILE];
 #pragma unroll
@@ -760,33 +758,48 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
         }
         __syncthreads();
         if (PF && tile + nsb < ntiles) load_tile(tile + nsb);     // next tile's loads fly under this tile's MFMAs
+        // dy fragments of all four output slices of this wave's row pair
+        bf16x8 A[WTZ][CO_B];
 #pragma unroll
-        for (int z = 0; z < WTZ; z++) {
-            bf16x8 A[CO_B];
+        for (int z = 0; z < WTZ; z++)
 #pragma unroll
             for (int a = 0; a < CO_B; a++) {
-                A[a] = tr_frag(dysb, laneA + z * (WTY * WTX * 32) + a * (WNV * 32));
+                A[z][a] = tr_frag(dysb, laneA + z * (WTY * WTX * 32) + a * (WNV * 32));
                 if (do_db) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) dbs[a] += (float)A[a][j];
+                    for (int j = 0; j < 8; j++) dbs[a] += (float)A[z][a][j];
                 }
             }
-            int boff = laneB + z * (WIY * WIX * 32);
-            // B fragments (tap, ci-block) stream through a PFD-deep register ring so that 2*PFD transposed LDS reads are
-            // in flight ahead of the MFMAs (the compiler alone keeps only 2 fragments ahead -> LDS latency exposed)
-            constexpr int NTB = NT * CI_B, PFD = 4;
-            auto bfrag = [&](int t) { return tr_frag(xsb, boff + tapOff[t / CI_B] + (t % CI_B) * (WNH * 32)); };
-            bf16x8 Bq[PFD];
+        // x fragments are walked by HALO slice zz = z + dz: one fragment (zz, dy, dx, ci-block) feeds the up to three
+        // (z, dz) pairs with z + dz = zz  ->  6*9 instead of 4*27 transposed LDS reads per ci-block (2x fewer).
+        // They stream through a PFD-deep register ring (2*PFD tr-reads in flight ahead of the MFMAs).
+        constexpr int NB = WIZ * NY * 3 * CI_B, PFD = 4;
+        auto bfrag = [&](int t) {
+            int b_ = t % CI_B, r = t / CI_B;
+            int dx = r % 3; r /= 3;
+            int dyi = r % NY, zz = r / NY;
+            int dy = (NT == 27) ? dyi : tg;
+            return tr_frag(xsb, laneB + ((zz * WIY + dy) * WIX + dx) * 32 + b_ * (WNH * 32));
+        };
+        bf16x8 Bq[PFD];
 #pragma unroll
-            for (int t = 0; t < PFD && t < NTB; t++) Bq[t] = bfrag(t);
+        for (int t = 0; t < PFD; t++) Bq[t] = bfrag(t);
 #pragma unroll
-            for (int t = 0; t < NTB; t++) {
-                bf16x8 Bc = Bq[t % PFD];
-                if (t + PFD < NTB) Bq[t % PFD] = bfrag(t + PFD);
-                int i = t / CI_B, b = t % CI_B;
+        for (int t = 0; t < NB; t++) {
+            bf16x8 Bc = Bq[t % PFD];
+            if (t + PFD < NB) Bq[t % PFD] = bfrag(t + PFD);
+            int b_ = t % CI_B, r = t / CI_B;
+            int dx = r % 3; r /= 3;
+            int dyi = r % NY, zz = r / NY;
 #pragma unroll
-                for (int a = 0; a < CO_B; a++)
-                    acc[(i * CO_B + a) * CI_B + b] = mfma16(A[a], Bc, acc[(i * CO_B + a) * CI_B + b]);
+            for (int dz = 0; dz < 3; dz++) {
+                int z = zz - dz;
+                if (z >= 0 && z < WTZ) {
+                    int i = (dz * NY + dyi) * 3 + dx;          // accumulator slot of tap (dz, dy, dx)
+#pragma unroll
+                    for (int a = 0; a < CO_B; a++)
+                        acc[(i * CO_B + a) * CI_B + b_] = mfma16(A[z][a], Bc, acc[(i * CO_B + a) * CI_B + b_]);
+                }
             }
         }
     }
@@ -798,7 +811,8 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
     int COBN = Cout / 16, CIBN = Cin / 16;
     reduce_waves<NTILE>(acc, red, wave, lane, [&](int idx, f32x4 sum) {
         int b = idx % CI_B, a = (idx / CI_B) % CO_B, i = idx / (CI_B * CO_B);
-        int tap = tg * NT + i;
+        int dx = i % 3, dyi = (i / 3) % NY, dz = i / (3 * NY);
+        int tap = dz * 9 + ((NT == 27) ? dyi : tg) * 3 + dx;
         int64_t tileIdx = ((int64_t)tap * COBN + (co0 / 16 + a)) * CIBN + (ci0 / 16 + b);
         *reinterpret_cast<f32x4*>(slab + tileIdx * 256 + lane * 4) = sum;
     });
