@@ -741,7 +741,7 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
         }
     };
     // prefetch the next tile into registers while computing (only where the register file has room for it)
-    constexpr bool PF = (NT * CO_B * CI_B > 27) && (NT * CO_B * CI_B + NA + NB) * 4 <= 250;
+    constexpr bool PF = (NT * CO_B * CI_B > 27) && (NT * CO_B * CI_B + NA + NB) * 4 <= 300;
     if (PF && sb < ntiles) load_tile(sb);
     for (int tile = sb; tile < ntiles; tile += nsb) {
         if (!PF) load_tile(tile);
@@ -953,15 +953,17 @@ struct WgCfg { int cob, cib, nt, tg, nsb; };
 inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     WgCfg c;
     c.cob = Cout % 32 == 0 ? 2 : 1;
-    // Cout = 16 (one co block): two passes of the lean <1,1,27> kernel (2 workgroups/CU, 108 accumulators) beat one
-    // <1,2,27> pass (216 accumulators, 85 KB LDS, 1 workgroup/CU) although dy is staged twice
-    c.cib = (Cin % 32 == 0 && Cout % 32 == 0) ? 2 : 1;
+    // One ci block and all 27 taps per workgroup.  The kernel is bound by L2->LDS tile traffic, so what counts is MFMAs
+    // per staged byte: <2,1,27> stages 67 KB per 216 MFMAs/wave, the old <2,2,9> tap-group split 101 KB per 144.
+    // Cout = 16: the lean <1,1,27> kernel (2 workgroups/CU, 108 accumulator registers).
+    c.cib = 1;
     int groups = (Cout / (16 * c.cob)) * (Cin / (16 * c.cib));
     int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
     int blocks = c.cob * c.cib;
-    c.nt = blocks <= 2 ? 27 : 9;
-    c.tg = 27 / c.nt;
-    int64_t want = 512 / ((int64_t)groups * c.tg);     // floor: total workgroups <= 2 per CU, no ragged third round
+    c.nt = 27;
+    c.tg = 1;
+    // persistent: one round of workgroups (1 per CU for the 216-accumulator kernel, 2 per CU for the lean one)
+    int64_t want = (blocks == 1 ? 512 : 256) / (int64_t)groups;
     if (want < 1) want = 1;
     c.nsb = (int)(ntiles < want ? ntiles : want);
     return c;
@@ -1007,8 +1009,7 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     int rc;
     if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
     else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
-    else if (c.cob == 1 && c.cib == 2) rc = launch_wgrad<1, 2, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
-    else rc = launch_wgrad<2, 2, 9>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    else { MI3D_CHECK_ARG(false, "conv3_mfma_wgrad: no kernel for this block config"); return -1; }
     MI3D_TRY(rc);
     slab_reduce2_kernel<true><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
     MI3D_LAUNCH_CHECK();
