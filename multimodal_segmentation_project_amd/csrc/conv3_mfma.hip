@@ -878,13 +878,18 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_c1_kernel(const float* __rest
                 v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)n * D + gz) * H + gy) * W + gx) * dycs + co0 + half * 8);
             *reinterpret_cast<bf16x8*>(dys + vox * 16 + half * 8) = v;
         }
-        for (int idx = threadIdx.x; idx < 3 * C1_ROWS * 16; idx += BLK) {
-            int xx = idx & 15, row = (idx >> 4) % C1_ROWS, dx = idx / (16 * C1_ROWS);
+        for (int idx = threadIdx.x; idx < C1_ROWS * WIX; idx += BLK) {
+            int h = idx % WIX, row = idx / WIX;
             int iy = row % WIY, iz = row / WIY;
-            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + xx + dx;
+            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + h;
             float v = 0.f;
             if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[(((int64_t)n * D + gz) * H + gy) * W + gx];
-            xsh[idx] = (bf16)v;
+            bf16 vb = (bf16)v;
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {           // copy dx holds x[.. + xx + dx] at xx = h - dx
+                int xx = h - dx;
+                if (xx >= 0 && xx < 16) xsh[(dx * C1_ROWS + row) * 16 + xx] = vb;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -918,22 +923,28 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_c1_kernel(const float* __rest
         slab[nW + co0 + threadIdx.x] = (red[threadIdx.x] + red[16 + threadIdx.x]) + (red[32 + threadIdx.x] + red[48 + threadIdx.x]);
 }
 
-// fixed-order parallel slab sum: block = 32 elements x 8 slab groups.  MFMA_LAYOUT: slab elements are in the
-// (tap, co-block, ci-block, lane, reg) order written above and are un-permuted to torch's (Cout, Cin, 27) here.
-template <bool MFMA_LAYOUT>
+// fixed-order parallel slab sum: block = EW elements x 256/EW slab groups (EW = 8 when the slab is small and the
+// parallelism has to come from the slab dimension).  MFMA_LAYOUT: slab elements are in the (tap, co-block, ci-block,
+// lane, reg) order written above and are un-permuted to torch's (Cout, Cin, 27) here.
+template <bool MFMA_LAYOUT, int EW>
 __global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
                                                            int64_t nW, float* __restrict__ dW, float* __restrict__ db,
                                                            int accumulate, int Cin, int Cout) {
-    __shared__ float red[8][32];
-    int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    int64_t i = (int64_t)blockIdx.x * 32 + e;
+    constexpr int SG = BLK / EW;
+    __shared__ float red[SG][EW];
+    int e = threadIdx.x % EW, sg = threadIdx.x / EW;
+    int64_t i = (int64_t)blockIdx.x * EW + e;
     float s = 0.f;
     if (i < slab_sz)
-        for (int b = sg; b < nslab; b += 8) s += slabs[(int64_t)b * slab_sz + i];
+        for (int b = sg; b < nslab; b += SG) s += slabs[(int64_t)b * slab_sz + i];
     red[sg][e] = s;
     __syncthreads();
     if (sg == 0 && i < slab_sz) {
-        float tsum = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < SG; k += 8)
+            tsum += ((red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e])) +
+                    ((red[k + 4][e] + red[k + 5][e]) + (red[k + 6][e] + red[k + 7][e]));
         if (i < nW) {
             int64_t o = i;
             if (MFMA_LAYOUT) {
@@ -945,6 +956,52 @@ __global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restri
             }
             if (dW) dW[o] = accumulate ? dW[o] + tsum : tsum;
         } else if (db) { db[i - nW] = accumulate ? db[i - nW] + tsum : tsum; }
+    }
+}
+
+// Large weight tensors (few slabs, MBs of output): one block per (co-block, ci-block, 4-row group G) sums the 27 tap
+// tiles' 64-float row groups (256 B contiguous reads), transposes through LDS and writes the four (co) rows'
+// contiguous 16 ci x 27 tap runs -- the scattered 4-byte stores of the kernel above cost 4x the time there.
+__global__ __launch_bounds__(BLK) void slab_reduce_tile_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
+                                                               int64_t nW, float* __restrict__ dW, float* __restrict__ db,
+                                                               int accumulate, int Cin, int Cout) {
+    __shared__ float out[4 * 16 * 27];
+    int CIBN = Cin / 16, COBN = Cout / 16;
+    int t = blockIdx.x;
+    int G = t & 3; t >>= 2;
+    int ib = t % CIBN, cb = t / CIBN;
+    constexpr int NE = (27 * 64 + BLK - 1) / BLK;
+    float acc[NE];
+    const float* p[NE];
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+        int e = threadIdx.x + k * BLK;
+        int tap = e < 27 * 64 ? (e >> 6) : 26, j = e & 63;
+        p[k] = slabs + (((int64_t)tap * COBN + cb) * CIBN + ib) * 256 + G * 64 + j;
+        acc[k] = 0.f;
+    }
+    for (int b = 0; b < nslab; b++) {              // NE independent 256 B-coalesced loads in flight per slab
+#pragma unroll
+        for (int k = 0; k < NE; k++) acc[k] += p[k][(int64_t)b * slab_sz];
+    }
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+        int e = threadIdx.x + k * BLK;
+        if (e < 27 * 64) { int tap = e >> 6, j = e & 63; out[((j & 3) * 16 + (j >> 2)) * 27 + tap] = acc[k]; }
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < 4 * 432; m += BLK) {
+        int r = m / 432, k = m - r * 432;
+        int64_t o = ((int64_t)(cb * 16 + 4 * G + r) * Cin + ib * 16) * 27 + k;
+        float v = out[m];
+        dW[o] = accumulate ? dW[o] + v : v;
+    }
+    if (db && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < Cout; c += BLK) {
+            float s = 0.f;
+            for (int b = 0; b < nslab; b++) s += slabs[(int64_t)b * slab_sz + nW + c];
+            db[c] = accumulate ? db[c] + s : s;
+        }
     }
 }
 
@@ -965,7 +1022,8 @@ inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     // persistent: one round of workgroups (1 per CU for the 216-accumulator kernel, 2 per CU for the lean one)
     int64_t want = (blocks == 1 ? 512 : 256) / (int64_t)groups;
     if (want < 1) want = 1;
-    c.nsb = (int)(ntiles < want ? ntiles : want);
+    int64_t rounds = cdiv(ntiles, want);               // tiles per workgroup; then the fewest slabs that keep it
+    c.nsb = (int)cdiv(ntiles, rounds);
     return c;
 }
 
@@ -1011,7 +1069,12 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
     else { MI3D_CHECK_ARG(false, "conv3_mfma_wgrad: no kernel for this block config"); return -1; }
     MI3D_TRY(rc);
-    slab_reduce2_kernel<true><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+    if (dW && slab_sz >= (800 << 10))
+        slab_reduce_tile_kernel<<<(Cout / 16) * (Cin / 16) * 4, BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+    else if (slab_sz < (16 << 10))
+        slab_reduce2_kernel<true, 8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+    else
+        slab_reduce2_kernel<true, 32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1027,7 +1090,7 @@ int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo 
     conv3_wgrad_c1_kernel<<<grid, BLK, 0, s>>>(x, (const bf16*)dy, dycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ), cdiv(g.H, WTY),
                                                cdiv(g.W, WTX), ws);
     MI3D_LAUNCH_CHECK();
-    slab_reduce2_kernel<false><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, 1, Cout);
+    slab_reduce2_kernel<false, 8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, 1, Cout);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -240,19 +240,25 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
     }
 }
 
+template <int EW>
 __global__ __launch_bounds__(BLK) void slab_reduce3_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
                                                            int64_t nW, float* __restrict__ dW, float* __restrict__ db,
                                                            int accumulate) {
-    __shared__ float red[8][32];
-    int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    int64_t i = (int64_t)blockIdx.x * 32 + e;
+    constexpr int SG = BLK / EW;                  // EW = 8 for small slabs: parallelism from the slab dimension
+    __shared__ float red[SG][EW];
+    int e = threadIdx.x % EW, sg = threadIdx.x / EW;
+    int64_t i = (int64_t)blockIdx.x * EW + e;
     float s = 0.f;
     if (i < slab_sz)
-        for (int b = sg; b < nslab; b += 8) s += slabs[(int64_t)b * slab_sz + i];
+        for (int b = sg; b < nslab; b += SG) s += slabs[(int64_t)b * slab_sz + i];
     red[sg][e] = s;
     __syncthreads();
     if (sg == 0 && i < slab_sz) {
-        float tsum = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < SG; k += 8)
+            tsum += ((red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e])) +
+                    ((red[k + 4][e] + red[k + 5][e]) + (red[k + 6][e] + red[k + 7][e]));
         if (i < nW) { if (dW) dW[i] = accumulate ? dW[i] + tsum : tsum; }
         else if (db) { db[i - nW] = accumulate ? db[i - nW] + tsum : tsum; }
     }
@@ -334,7 +340,8 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         dim3 grid((unsigned)nsb, (unsigned)(Cin / 32), (unsigned)cdiv(Cout, 32));
         upconv_mfma_bwd_weight_kernel<<<grid, BLK, lds, s>>>(xp, xcs, Cin, gp, gycs, Cout, g.N, g.D, g.H, g.W, ws);
         MI3D_LAUNCH_CHECK();
-        slab_reduce3_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
+        if (slab_sz < (16 << 10)) slab_reduce3_kernel<8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
+        else slab_reduce3_kernel<32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
         MI3D_LAUNCH_CHECK();
     }
     return 0;
