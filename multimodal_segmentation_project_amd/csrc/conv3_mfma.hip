@@ -63,6 +63,68 @@ __global__ void pack_mfma_kernel(const float* __restrict__ w, int Cin, int Cout,
     }
 }
 
+// One launch for every pack of the network.  conv3 unit = one (co-block, ci-block) pair of a layer: its 16 x (16*27)
+// source floats are read as 16 contiguous 1.7 KB runs into LDS and both images (forward, dgrad) of the pair are
+// written as 16-byte stores; upconv unit = 2048 packed elements (layout of upconv_mfma.hip, gathered directly).
+constexpr int PK_LD = 16 * 27 + 1;
+__global__ __launch_bounds__(BLK) void pack_all_kernel(PackJobs J) {
+    __shared__ float wl[16 * PK_LD];
+    int b = blockIdx.x, ji = 0;
+    while (ji + 1 < J.n && b >= J.j[ji + 1].blk0) ji++;
+    const float* __restrict__ w = J.j[ji].w;
+    int Cin = J.j[ji].Cin, Cout = J.j[ji].Cout, lb = b - J.j[ji].blk0;
+    if (J.j[ji].kind == 0) {
+        bf16* wf = (bf16*)J.j[ji].a; bf16* wd = (bf16*)J.j[ji].b;
+        int mode_f = J.j[ji].mode_f, mode_d = J.j[ji].mode_d;
+        int CIBN = Cin / 16, COBN = Cout / 16;
+        int cib = lb % CIBN, cob = lb / CIBN;
+        for (int idx = threadIdx.x; idx < 16 * 432; idx += BLK) {
+            int row = idx / 432, k = idx - row * 432;
+            wl[row * PK_LD + k] = w[((int64_t)(cob * 16 + row) * Cin + cib * 16) * 27 + k];
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < 2 * 14 * 64; q += BLK) {
+            int img = q / (14 * 64), r = q - img * (14 * 64);
+            int s = r >> 6, lane = r & 63, g = lane >> 4, o = lane & 15;
+            int tap = ktap(img ? mode_d : mode_f, s, g >> 1);
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int ic = 8 * (g & 1) + j;
+                float f = 0.f;
+                if (tap < 27) f = img ? wl[ic * PK_LD + o * 27 + (26 - tap)] : wl[o * PK_LD + ic * 27 + tap];
+                v[j] = (bf16)f;
+            }
+            bf16* dst = img ? wd + ((((int64_t)cob * 14 + s) * CIBN + cib) * 64 + lane) * 8
+                            : wf + ((((int64_t)cib * 14 + s) * COBN + cob) * 64 + lane) * 8;
+            *reinterpret_cast<bf16x8*>(dst) = v;
+        }
+    } else {
+        bf16* wf = (bf16*)J.j[ji].a; bf16* wb = (bf16*)J.j[ji].b;
+        int64_t n = (int64_t)Cin * Cout * 8;
+        int KS = Cin / 32, COBN = Cout / 16, S = Cout / 4;
+        int64_t k0 = ((int64_t)lb * BLK + threadIdx.x) * 8;
+        if (k0 >= 2 * n) return;
+        bool bw = k0 >= n;
+        int64_t k = bw ? k0 - n : k0;
+        int lane = (k >> 3) & 63, G = lane >> 4;
+        int64_t r = k >> 9;
+        bf16x8 v;
+        if (!bw) {
+            int ks = r % KS; r /= KS; int cb = r % COBN; int tap = r / COBN;
+            int co = cb * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (bf16)w[((int64_t)(32 * ks + 8 * G + j) * Cout + co) * 8 + tap];
+        } else {
+            int s = r % S; int cib = r / S;
+            int kk0 = 32 * s + 8 * G, tap = kk0 / Cout, co0 = kk0 % Cout, ci = cib * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (bf16)w[((int64_t)ci * Cout + co0 + j) * 8 + tap];
+        }
+        *reinterpret_cast<bf16x8*>((bw ? wb : wf) + k) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ kernel
 // SPLITK: blockIdx.z owns a contiguous range of 16-channel input chunks and writes fp32 partial outputs
 // part[kz][voxel][CoutTotal] (no bias / statistics); splitk_finish_kernel sums them.  Used for the deep levels
@@ -576,6 +638,28 @@ int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dg
     int mode_f = persist_ok(Cin, Cout, g) ? 1 : 0, mode_d = persist_ok(Cout, Cin, g) ? 1 : 0;
     pack_mfma_kernel<<<cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256), 256, 0, s>>>(w, Cin, Cout, (bf16*)wp_fwd, (bf16*)wp_dgrad,
                                                                              mode_f, mode_d);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g) {
+    MI3D_CHECK_ARG(J.n < MAX_PACK_JOBS && Cin % 16 == 0 && Cout % 16 == 0, "pack_all: too many jobs / bad channels");
+    PackJob& j = J.j[J.n++];
+    j = PackJob{w, wp_fwd, wp_dgrad, Cin, Cout, 0, persist_ok(Cin, Cout, g) ? 1 : 0, persist_ok(Cout, Cin, g) ? 1 : 0, J.nblocks};
+    J.nblocks += (Cin / 16) * (Cout / 16);
+    return 0;
+}
+int pack_all_add_upconv(PackJobs& J, const float* w, int Cin, int Cout, void* wp) {
+    MI3D_CHECK_ARG(J.n < MAX_PACK_JOBS, "pack_all: too many jobs");
+    int64_t n = (int64_t)Cin * Cout * 8;
+    PackJob& j = J.j[J.n++];
+    j = PackJob{w, wp, (bf16*)wp + n, Cin, Cout, 1, 0, 0, J.nblocks};
+    J.nblocks += (int)cdiv(2 * n, (int64_t)BLK * 8);
+    return 0;
+}
+int pack_all_launch(const PackJobs& J, hipStream_t s) {
+    if (J.n == 0) return 0;
+    pack_all_kernel<<<J.nblocks, BLK, 0, s>>>(J);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -29,6 +29,14 @@ int conv3_direct_wgrad(int x_dtype, int dy_dtype, const void* x, int xcs, int Ci
 bool conv3_mfma_supported(int Cin, int Cout, int xcs, int ycs);
 size_t conv3_mfma_pack_elems(int Cin, int Cout);             // bf16 elements of ONE packed operand
 int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g, hipStream_t s);
+// All weight packs of a network in ONE launch (every kernel node of the step graph costs ~4.5 us of dispatch floor):
+// jobs are appended on the host, the kernel finds its job from the block index.
+struct PackJob { const float* w; void* a; void* b; int Cin, Cout, kind, mode_f, mode_d, blk0; };   // kind 0 conv3, 1 upconv
+constexpr int MAX_PACK_JOBS = 32;
+struct PackJobs { int n, nblocks; PackJob j[MAX_PACK_JOBS]; };
+int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g);
+int pack_all_add_upconv(PackJobs& J, const float* w, int Cin, int Cout, void* wp);
+int pack_all_launch(const PackJobs& J, hipStream_t s);
 int conv3_mfma_stat_blocks(int Cin, int Cout, Geo g);                           // partials written when `part` != NULL
 // dgrad = same call with the dgrad pack and (Cin,Cout) swapped, bias NULL, part NULL
 size_t conv3_mfma_splitk_floats(int Cin, int Cout, Geo g);    // K-split scratch for deep (small-M) layers, 0 = none

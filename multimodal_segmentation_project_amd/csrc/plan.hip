@@ -165,6 +165,7 @@ struct Ctx {
     hipStream_t s2 = nullptr;
     hipEvent_t* ev = nullptr;
     mutable int seq = 0;
+    mutable bool packed = false;      // weight packs already done by the one-launch pack_all
     template <typename T = void> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
     const float* P(int i) const { return reinterpret_cast<const float*>(params[i]); }
 };
@@ -204,7 +205,7 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
         bool fused_stats = false;
         if (H.mfma) {
-            MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
+            if (!c.packed) MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
                                     training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s));
             fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
@@ -337,6 +338,21 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
     int L = p.L;
     if (d->in_channels > 1)
         MI3D_TRY(ncdhw_to_ndhwc(p.dt, x, c.at(p.xcl), d->in_channels, d->in_channels, d->N, p.geo[0].V(), c.s));
+    {   // every MFMA weight pack of the network in one launch
+        PackJobs J;
+        J.n = 0; J.nblocks = 0;
+        for (int b = 0; b < p.nblk; b++)
+            for (int h = 0; h < 2; h++) {
+                const HalfP& H = p.blk[b].h[h];
+                if (H.mfma) MI3D_TRY(pack_all_add_conv3(J, c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), p.geo[p.blk[b].level]));
+            }
+        for (int i = 0; i < L; i++) {
+            int l = L - 1 - i;
+            if (p.up_mfma[i]) MI3D_TRY(pack_all_add_upconv(J, c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i])));
+        }
+        MI3D_TRY(pack_all_launch(J, c.s));
+        c.packed = true;
+    }
     for (int l = 0; l < L; l++) {
         MI3D_TRY(block_forward(c, l, x, buffers, drop_scales, training));
         MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), 2 * p.C[l], p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
@@ -350,7 +366,7 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
         const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
         char* catl = c.at<char>(p.cat[l]);
         if (p.up_mfma[i]) {
-            MI3D_TRY(upconv2_mfma_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i]), c.s));
+            if (!c.packed) MI3D_TRY(upconv2_mfma_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i]), c.s));
             MI3D_TRY(upconv2_mfma_fwd(uin, 2 * p.C[l], 2 * p.C[l], c.at(p.upw[i]), c.P(p.up_pidx(i) + 1),
                                       catl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l], p.geo[l + 1], c.s));
         } else {
