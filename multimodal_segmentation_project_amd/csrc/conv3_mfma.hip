@@ -343,7 +343,7 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
                                                                     const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                                     bf16* __restrict__ y, int ycs, int D, int H, int W,
                                                                     int tilesZ, int tilesY, int tilesX, int ntiles,
-                                                                    float* __restrict__ part) {
+                                                                    float* __restrict__ part, Halves xh, Halves yh) {
     constexpr int TZ = 4, TY = 8, TX = 16, IZ = 6, IY = 10, IX = 18, MB = 8;
     constexpr int NVOX = IZ * IY * IX, NIT = (NVOX * 2 + BLK - 1) / BLK;
     constexpr int CoutTotal = COB * 16;
@@ -406,7 +406,8 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
         tile_origin(tile, n, z0, y0, x0);
         // element offset of halo voxel (0,0,0) of this tile (may point before the volume for border tiles: only
         // dereferenced where the coordinate test passes)
-        int64_t base = ((((int64_t)n * D + (z0 - 1)) * H + (y0 - 1)) * W + (x0 - 1)) * xcs + chunk * 16;
+        int64_t base = ((((int64_t)n * D + (z0 - 1)) * H + (y0 - 1)) * W + (x0 - 1)) * xcs + chunk * 16 +
+                       (chunk >= xh.split ? xh.delta : 0);
         const bf16* xb = x + base;
         bool interior = z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
         if (interior) {
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
                     o[j] = (bf16)(acc[r][c][j] + bv[c][j]);
                     if (STATS) { float q = ok ? (float)o[j] : 0.f; s1[c][j] += q; s2[c][j] = fmaf(q, q, s2[c][j]); }
                 }
-                if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs + c * 16) = o;
+                if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs + c * 16 + (c >= yh.split ? yh.delta : 0)) = o;
             }
         }
     }
@@ -681,8 +682,11 @@ bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g) { return pick_ksplit(Cin, 
 
 // y = conv(x, wp) (+ bias); part != NULL -> also write BN partial sums [nblk][2][Cout] of the rounded outputs
 // (only when conv3_mfma_fuses_stats); skws = K-split scratch (conv3_mfma_splitk_floats) or NULL to force single pass
+bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g) { return persist_ok(Cin, Cout, g); }
+
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
-                   float* part, float* skws, hipStream_t s) {
+                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh) {
+    MI3D_CHECK_ARG((!xh.on() && !yh.on()) || persist_ok(Cin, Cout, g), "conv3_mfma_fwd: planar halves need the persistent kernel");
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, ycs), "conv3_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
     MI3D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, "conv3_mfma_fwd: misaligned tensors");
     const bf16* xp = (const bf16*)x; const bf16* w = (const bf16*)wp; bf16* yp = (bf16*)y;
@@ -691,8 +695,8 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         int tz = cdiv(g.D, 4), ty = cdiv(g.H, 8), tx = cdiv(g.W, 16), nt = g.N * tz * ty * tx, grid = persist_grid(Cin, Cout, g);
 #define PK(COB_, NCH_)                                                                                                         \
         do {                                                                                                                   \
-            if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part); \
-            else conv3_mfma_persist_kernel<COB_, NCH_, false><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr); \
+            if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh); \
+            else conv3_mfma_persist_kernel<COB_, NCH_, false><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh); \
         } while (0)
         if (Cin == 16 && Cout == 16) PK(1, 1);
         else if (Cin == 32) PK(1, 2);
@@ -766,7 +770,7 @@ template <int CO_B, int CI_B, int NT>
 __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                                const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
                                                                int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
-                                                               float* __restrict__ slabs) {
+                                                               float* __restrict__ slabs, Halves xh) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16* dys = reinterpret_cast<bf16*>(lds_raw);                 // [CO_B][WNV][16]
     bf16* xs = dys + CO_B * WNV * 16;                             // [CI_B][WNH][16]
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
         int tz_ = t % tilesZ; int n = t / tilesZ;
         int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
         const bf16* dyn = dy + (int64_t)n * D * H * W * dycs + co0;
-        const bf16* xn = x + (int64_t)n * D * H * W * xcs + ci0;
+        const bf16* xn = x + (int64_t)n * D * H * W * xcs + ci0 + ((ci0 >> 4) >= xh.split ? xh.delta : 0);
 #pragma unroll
         for (int it = 0; it < NA; it++) {
             int idx = threadIdx.x + it * BLK;
@@ -1113,7 +1117,7 @@ inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
 
 template <int CO_B, int CI_B, int NT>
 int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int Cout, Geo g, float* slabs, WgCfg c,
-                 hipStream_t s) {
+                 hipStream_t s, Halves xh) {
     static bool attr_set = false;
     size_t lds = (size_t)(CO_B * WNV + CI_B * WNH) * 32;
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
@@ -1124,7 +1128,7 @@ int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int 
     }
     dim3 grid((unsigned)(c.nsb * c.tg), (unsigned)(Cout / (16 * CO_B)), (unsigned)(Cin / (16 * CI_B)));
     conv3_wgrad_mfma_kernel<CO_B, CI_B, NT><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W,
-                                                                  cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs);
+                                                                  cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1142,15 +1146,15 @@ size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g) {
 }
 
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
-                     int accumulate, float* ws, size_t ws_floats, hipStream_t s) {
+                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh) {
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0, "conv3_mfma_wgrad: unsupported channels");
     WgCfg c = wgrad_cfg(Cin, Cout, g);
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
     MI3D_CHECK_ARG(ws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_wgrad: workspace too small");
     const bf16* xp = (const bf16*)x; const bf16* dp = (const bf16*)dy;
     int rc;
-    if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
-    else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s);
+    if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s, xh);
+    else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s, xh);
     else { MI3D_CHECK_ARG(false, "conv3_mfma_wgrad: no kernel for this block config"); return -1; }
     MI3D_TRY(rc);
     if (dW && slab_sz >= (800 << 10))

@@ -41,12 +41,17 @@ int conv3_mfma_stat_blocks(int Cin, int Cout, Geo g);                           
 // dgrad = same call with the dgrad pack and (Cin,Cout) swapped, bias NULL, part NULL
 size_t conv3_mfma_splitk_floats(int Cin, int Cout, Geo g);    // K-split scratch for deep (small-M) layers, 0 = none
 bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g);        // false -> caller runs bn_train_stats afterwards
+// A tensor whose channels live in TWO planes of the same stride ("planar halves" of a skip/up concat buffer):
+// 16-channel block b >= split is found `delta` elements further than the single-plane address would say.
+// Default = ordinary single-plane tensor.  Only the persistent full-resolution kernels and wgrad honour it.
+struct Halves { int split = 1 << 30; int64_t delta = 0; bool on() const { return delta != 0; } };
+bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g);          // forward (Cin,Cout) launch can take Halves x / y
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
-                   Geo g, float* part, float* skws, hipStream_t s);
+                   Geo g, float* part, float* skws, hipStream_t s, Halves xh = Halves(), Halves yh = Halves());
 
 size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
-                     int accumulate, float* ws, size_t ws_floats, hipStream_t s);
+                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh = Halves());
 
 int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db, int accumulate,
                         float* ws, size_t ws_floats, hipStream_t s);

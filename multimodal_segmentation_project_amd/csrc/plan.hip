@@ -40,6 +40,17 @@ struct Plan {
     int nblk;
     size_t cat[MAXL], pool[MAXL], zb, zd[MAXL], upw[MAXL], xcl;
     bool up_mfma[MAXL];
+    // planar[l]: the level's concat buffers cat[l] / gcat[l] hold the skip half and the up half as two [M][C] planes
+    // instead of one interleaved [M][2C] tensor.  With C = 16 the interleaved halves are 32 B pieces of 64 B rows and
+    // every kernel that touches ONE half (bn apply, max-pool fwd/bwd, upconv fwd/bwd) wastes half of each line.
+    bool planar[MAXL];
+    int catcs(int l) const { return planar[l] ? C[l] : 2 * C[l]; }
+    size_t half_off(int l) const { return (planar[l] ? (size_t)geo[l].M() * C[l] : (size_t)C[l]) * esz; }   // bytes to the up half
+    Halves halves(int l) const {
+        Halves h;
+        if (planar[l]) { h.split = C[l] / 16; h.delta = geo[l].M() * C[l] - C[l]; }
+        return h;
+    }
     size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sB2, sC;
     size_t bnws, wgws, wgws2, statpart, skws;
     size_t wgws_floats;
@@ -74,6 +85,9 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     MI3D_CHECK_ARG(p.C[p.L] <= 256, "bottleneck width %d > 256", p.C[p.L]);
     for (int l = 0; l <= p.L; l++) p.geo[l] = Geo{d->N, d->D >> l, d->H >> l, d->W >> l};
 
+    for (int l = 0; l < p.L; l++)
+        p.planar[l] = p.dt == MI3D_BF16 && p.C[l] % 16 == 0 && conv3_mfma_halves_ok(2 * p.C[l], p.C[l], p.geo[l]) &&
+                      conv3_mfma_halves_ok(p.C[l], 2 * p.C[l], p.geo[l]) && !getenv("MI3D_FORCE_DIRECT") && !getenv("MI3D_NO_PLANAR");
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     int64_t drop_off = 0;
@@ -178,12 +192,12 @@ void block_input(const Ctx& c, int b, const float* x, const void*& ptr, int& cs,
         if (p.d.in_channels == 1) { ptr = x; cs = 1; dt = MI3D_F32; }
         else { ptr = c.at(p.xcl); cs = p.d.in_channels; }
     } else if (b <= p.L) { ptr = c.at(p.pool[b - 1]); cs = p.C[b - 1]; }
-    else { int l = p.blk[b].level; ptr = c.at(p.cat[l]); cs = 2 * p.C[l]; }
+    else { int l = p.blk[b].level; ptr = c.at(p.cat[l]); cs = p.catcs(l); }
 }
 // output tensor (z2) of block b
 void block_output(const Ctx& c, int b, void*& ptr, int& cs) {
     const Plan& p = c.p;
-    if (b < p.L) { ptr = c.at(p.cat[b]); cs = 2 * p.C[b]; }
+    if (b < p.L) { ptr = c.at(p.cat[b]); cs = p.catcs(b); }
     else if (b == p.L) { ptr = c.at(p.zb); cs = p.C[p.L]; }
     else { ptr = c.at(p.zd[b - p.L - 1]); cs = p.C[p.blk[b].level]; }
 }
@@ -207,7 +221,8 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         if (H.mfma) {
             if (!c.packed) MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
-                                    training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s));
+                                    training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
+                                    (h == 0 && b > p.L) ? p.halves(B.level) : Halves()));
             fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
         } else {
             MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), c.at<float>(H.wpd), c.s));
@@ -265,7 +280,7 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             }
             if (H.mfma)
                 MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
-                                          wgws, p.wgws_floats, ws_));
+                                          wgws, p.wgws_floats, ws_, (h == 0 && b > p.L) ? p.halves(B.level) : Halves()));
             else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT"))
                 MI3D_TRY(conv3_mfma_wgrad_c1((const float*)in, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
                                              wgws, p.wgws_floats, ws_));
@@ -279,7 +294,8 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         if (dx) {
             if (H.mfma)
                 MI3D_TRY(conv3_mfma_fwd(dyb, H.Cout, H.Cout, c.at(H.wpd), nullptr, dx, dxs, H.Cin, g, nullptr,
-                                        (dxs % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s));
+                                        (dxs % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s, Halves(),
+                                        (h == 0 && b > p.L) ? p.halves(B.level) : Halves()));
             else
                 MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, dyb, H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
         }
@@ -355,7 +371,7 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
     }
     for (int l = 0; l < L; l++) {
         MI3D_TRY(block_forward(c, l, x, buffers, drop_scales, training));
-        MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), 2 * p.C[l], p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
+        MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), p.catcs(l), p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
     }
     MI3D_TRY(block_forward(c, L, x, buffers, drop_scales, training));
     if (gap_out) MI3D_TRY(gap_fwd(p.dt, c.at(p.zb), p.C[L], p.C[L], d->N, p.geo[L].V(), gap_out, c.s));
@@ -368,11 +384,11 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
         if (p.up_mfma[i]) {
             if (!c.packed) MI3D_TRY(upconv2_mfma_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i]), c.s));
             MI3D_TRY(upconv2_mfma_fwd(uin, 2 * p.C[l], 2 * p.C[l], c.at(p.upw[i]), c.P(p.up_pidx(i) + 1),
-                                      catl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l], p.geo[l + 1], c.s));
+                                      catl + p.half_off(l), p.catcs(l), p.C[l], p.geo[l + 1], c.s));
         } else {
             MI3D_TRY(upconv2_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], wf, wb, c.s));
-            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + (size_t)p.C[l] * p.esz,
-                                 2 * p.C[l], p.C[l], p.geo[l + 1], c.s));
+            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + p.half_off(l),
+                                 p.catcs(l), p.C[l], p.geo[l + 1], c.s));
         }
         MI3D_TRY(block_forward(c, L + 1 + i, x, buffers, drop_scales, training));
     }
@@ -405,17 +421,17 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
         } else if (seg <= L) {
             if (!dlogits) continue;
             int l = seg - 1, i = L - 1 - l;       // decoder.i works at level l
-            MI3D_TRY(block_backward(c, L + 1 + i, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], c.at(p.gcat[l]), 2 * p.C[l], accumulate));
+            MI3D_TRY(block_backward(c, L + 1 + i, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], c.at(p.gcat[l]), p.catcs(l), accumulate));
             const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
             float* wf = c.at<float>(p.upw[i]);
             float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
             char* gcatl = c.at<char>(p.gcat[l]);
             if (p.up_mfma[i])
-                MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gcatl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l],
+                MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gcatl + p.half_off(l), p.catcs(l), p.C[l],
                                           c.at(p.upw[i]), c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1),
                                           accumulate, wgws, p.wgws_floats, p.geo[l + 1], c.s));
             else
-                MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gcatl + (size_t)p.C[l] * p.esz, 2 * p.C[l], p.C[l], wb,
+                MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gcatl + p.half_off(l), p.catcs(l), p.C[l], wb,
                                      c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1), accumulate, wgws,
                                      p.wgws_floats, p.geo[l + 1], c.s));
         } else if (seg == L + 1) {
@@ -424,8 +440,8 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
             MI3D_TRY(block_backward(c, L, x, grads, drop_scales, c.at(p.gz[L]), p.C[L], c.at(p.gp[L - 1]), p.C[L - 1], accumulate));
         } else {
             int l = 2 * L + 1 - seg;              // encoder.l
-            MI3D_TRY(maxpool2_bwd(p.dt, c.at(p.gp[l]), p.C[l], c.at(p.cat[l]), 2 * p.C[l], dlogits ? c.at(p.gcat[l]) : nullptr,
-                                  2 * p.C[l], c.at(p.gz[l]), p.C[l], p.C[l], p.geo[l], c.s));
+            MI3D_TRY(maxpool2_bwd(p.dt, c.at(p.gp[l]), p.C[l], c.at(p.cat[l]), p.catcs(l), dlogits ? c.at(p.gcat[l]) : nullptr,
+                                  p.catcs(l), c.at(p.gz[l]), p.C[l], p.C[l], p.geo[l], c.s));
             void* dx = l > 0 ? c.at(p.gp[l - 1]) : nullptr;
             MI3D_TRY(block_backward(c, l, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], dx, l > 0 ? p.C[l - 1] : 0, accumulate));
         }
