@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi3d.so")
+LIB_PATH = os.environ.get("MI3D_LIB_PATH") or os.path.join(_HERE, "libmi3d.so")   # override: A/B-test another build
 MAX_LEVELS = 6
 LOSS_COEF_FLOATS = 20
 DTYPE_F32, DTYPE_BF16 = 0, 1

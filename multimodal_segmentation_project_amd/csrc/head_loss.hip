@@ -36,84 +36,114 @@ __device__ __forceinline__ void load_cin_block(const T* zp, int nci, float (&zv)
     }
 }
 
-// logits[n][co][v] = bias[co] + sum_ci z[n,v,ci] * w[co][ci]       (Cout <= MAXC per blockIdx.y group)
-template <typename T, bool VEC>
+// logits[n][co][v] = bias[co] + sum_ci z[n,v,ci] * w[co][ci]       (Cout <= NCO per blockIdx.z group)
+// grid = (blocks over voxel groups, N, cout groups); a thread owns VV consecutive voxels of one sample so the fp32
+// class planes are written as 16-byte stores and no per-voxel 64-bit division is needed.
+template <typename T, bool VEC, int NCO, int VV>
 __global__ __launch_bounds__(BLK) void conv1_fwd_kernel(const T* __restrict__ z, int zcs, int Cin, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ logits, int Cout,
-                                                        int N, int64_t V) {
-    int64_t M = (int64_t)N * V;
-    int co0 = blockIdx.y * MAXC;
-    int nco = min(MAXC, Cout - co0);
-    for (int64_t m = (int64_t)blockIdx.x * BLK + threadIdx.x; m < M; m += (int64_t)gridDim.x * BLK) {
-        float acc[MAXC];
+                                                        int64_t V) {
+    int n = blockIdx.y;
+    int co0 = blockIdx.z * NCO;
+    int nco = min(NCO, Cout - co0);
+    const T* zn = z + (int64_t)n * V * zcs;
+    float* ln = logits + ((int64_t)n * Cout + co0) * V;
+    int64_t ngrp = V / VV;
+    for (int64_t grp = (int64_t)blockIdx.x * BLK + threadIdx.x; grp < ngrp; grp += (int64_t)gridDim.x * BLK) {
+        int64_t v0 = grp * VV;
+        float acc[NCO][VV];
 #pragma unroll
-        for (int j = 0; j < MAXC; j++) acc[j] = (bias && j < nco) ? bias[co0 + j] : 0.f;
+        for (int j = 0; j < NCO; j++)
+#pragma unroll
+            for (int k = 0; k < VV; k++) acc[j][k] = (bias && j < nco) ? bias[co0 + j] : 0.f;
         for (int c0 = 0; c0 < Cin; c0 += CINB) {
-            float zv[CINB];
             int nci = min(CINB, Cin - c0);
-            load_cin_block<T, VEC>(z + m * zcs + c0, nci, zv);
 #pragma unroll
-            for (int j = 0; j < MAXC; j++) {
-                if (j < nco) {
+            for (int k = 0; k < VV; k++) {
+                float zv[CINB];
+                load_cin_block<T, VEC>(zn + (v0 + k) * zcs + c0, nci, zv);
 #pragma unroll
-                    for (int i = 0; i < CINB; i++)
-                        if (VEC || i < nci) acc[j] = fmaf(zv[i], w[(int64_t)(co0 + j) * Cin + c0 + i], acc[j]);
+                for (int j = 0; j < NCO; j++) {
+                    if (j < nco) {
+#pragma unroll
+                        for (int i = 0; i < CINB; i++)
+                            if (VEC || i < nci) acc[j][k] = fmaf(zv[i], w[(int64_t)(co0 + j) * Cin + c0 + i], acc[j][k]);
+                    }
                 }
             }
         }
-        int64_t n = m / V, v = m - n * V;
 #pragma unroll
-        for (int j = 0; j < MAXC; j++)
-            if (j < nco) logits[((int64_t)n * Cout + co0 + j) * V + v] = acc[j];
+        for (int j = 0; j < NCO; j++) {
+            if (j < nco) {
+                if constexpr (VV == 4) *reinterpret_cast<float4*>(ln + (int64_t)j * V + v0) = float4{acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+                else ln[(int64_t)j * V + v0] = acc[j][0];
+            }
+        }
     }
 }
 
-// per block (blockIdx.y = 16-channel input block): dz[v][ci] = sum_co dl[co][v] w[co][ci];
-// slab[blockIdx.x] = { dW[co][ci] partial, db[co] partial }
-template <typename T, bool VEC, int NCO>
+// per block (blockIdx.z = 16-channel input block): dz[v][ci] = sum_co dl[co][v] w[co][ci];
+// slab[blockIdx.y * gridDim.x + blockIdx.x] = { dW[co][ci] partial, db[co] partial }
+template <typename T, bool VEC, int NCO, int VV>
 __global__ __launch_bounds__(BLK) void conv1_bwd_kernel(const T* __restrict__ z, int zcs, int Cin, const float* __restrict__ w,
                                                         const float* __restrict__ dl, int Cout, T* __restrict__ dz, int dzcs,
-                                                        int N, int64_t V, float* __restrict__ slabs) {
+                                                        int64_t V, float* __restrict__ slabs) {
     __shared__ float red[4][NCO * CINB + NCO];
-    int64_t M = (int64_t)N * V;
-    int c0 = blockIdx.y * CINB;
+    int n = blockIdx.y;
+    int c0 = blockIdx.z * CINB;
     int nci = min(CINB, Cin - c0);
-    float aw[NCO][CINB], ab[NCO];
+    const T* zn = z + (int64_t)n * V * zcs + c0;
+    T* dzn = dz ? dz + (int64_t)n * V * dzcs + c0 : nullptr;
+    const float* dln = dl + (int64_t)n * Cout * V;
+    float aw[NCO][CINB], ab[NCO], wr[NCO][CINB];
 #pragma unroll
     for (int j = 0; j < NCO; j++) {
         ab[j] = 0.f;
 #pragma unroll
-        for (int i = 0; i < CINB; i++) aw[j][i] = 0.f;
+        for (int i = 0; i < CINB; i++) { aw[j][i] = 0.f; wr[j][i] = (j < Cout && i < nci) ? w[(int64_t)j * Cin + c0 + i] : 0.f; }
     }
-    for (int64_t m = (int64_t)blockIdx.x * BLK + threadIdx.x; m < M; m += (int64_t)gridDim.x * BLK) {
-        int64_t n = m / V, v = m - n * V;
-        float g[NCO], zv[CINB], o[CINB];
-#pragma unroll
-        for (int j = 0; j < NCO; j++) g[j] = j < Cout ? dl[((int64_t)n * Cout + j) * V + v] : 0.f;
-        load_cin_block<T, VEC>(z + m * zcs + c0, nci, zv);
-#pragma unroll
-        for (int i = 0; i < CINB; i++) o[i] = 0.f;
+    int64_t ngrp = V / VV;
+    for (int64_t grp = (int64_t)blockIdx.x * BLK + threadIdx.x; grp < ngrp; grp += (int64_t)gridDim.x * BLK) {
+        int64_t v0 = grp * VV;
+        float g[NCO][VV];
 #pragma unroll
         for (int j = 0; j < NCO; j++) {
             if (j < Cout) {
-                ab[j] += g[j];
-#pragma unroll
-                for (int i = 0; i < CINB; i++) {
-                    aw[j][i] = fmaf(g[j], zv[i], aw[j][i]);
-                    if (VEC || i < nci) o[i] = fmaf(g[j], w[(int64_t)j * Cin + c0 + i], o[i]);
-                }
-            }
-        }
-        if (dz) {
-            if constexpr (VEC) {
-                float lo[8], hi[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) { lo[i] = o[i]; hi[i] = o[8 + i]; }
-                st8<T>(dz + m * dzcs + c0, lo);
-                st8<T>(dz + m * dzcs + c0 + 8, hi);
+                if constexpr (VV == 4) {
+                    float4 t = *reinterpret_cast<const float4*>(dln + (int64_t)j * V + v0);
+                    g[j][0] = t.x; g[j][1] = t.y; g[j][2] = t.z; g[j][3] = t.w;
+                } else g[j][0] = dln[(int64_t)j * V + v0];
             } else {
 #pragma unroll
-                for (int i = 0; i < CINB; i++) if (i < nci) dz[m * dzcs + c0 + i] = from_f<T>(o[i]);
+                for (int k = 0; k < VV; k++) g[j][k] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VV; k++) {
+            float zv[CINB], o[CINB];
+            load_cin_block<T, VEC>(zn + (v0 + k) * zcs, nci, zv);
+#pragma unroll
+            for (int i = 0; i < CINB; i++) o[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCO; j++) {
+                ab[j] += g[j][k];
+#pragma unroll
+                for (int i = 0; i < CINB; i++) {
+                    aw[j][i] = fmaf(g[j][k], zv[i], aw[j][i]);
+                    o[i] = fmaf(g[j][k], wr[j][i], o[i]);
+                }
+            }
+            if (dzn) {
+                if constexpr (VEC) {
+                    float lo[8], hi[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { lo[i] = o[i]; hi[i] = o[8 + i]; }
+                    st8<T>(dzn + (v0 + k) * dzcs, lo);
+                    st8<T>(dzn + (v0 + k) * dzcs + 8, hi);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CINB; i++) if (i < nci) dzn[(v0 + k) * dzcs + i] = from_f<T>(o[i]);
+                }
             }
         }
     }
@@ -122,94 +152,135 @@ __global__ __launch_bounds__(BLK) void conv1_bwd_kernel(const T* __restrict__ z,
     for (int j = 0; j < NCO; j++) {
 #pragma unroll
         for (int i = 0; i < CINB; i++) {
-            float s = wave_sum(aw[j][i]);
-            if (lane == 0) red[wave][j * CINB + i] = s;
+            float sv = wave_sum(aw[j][i]);
+            if (lane == 0) red[wave][j * CINB + i] = sv;
         }
         float sb = wave_sum(ab[j]);
         if (lane == 0) red[wave][NCO * CINB + j] = sb;
     }
     __syncthreads();
     int64_t nW = (int64_t)Cout * Cin;
-    float* slab = slabs + (int64_t)blockIdx.x * (nW + Cout);
+    float* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (nW + Cout);
     for (int idx = threadIdx.x; idx < NCO * CINB + NCO; idx += BLK) {
-        float s = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+        float sv = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
         if (idx < NCO * CINB) {
             int j = idx / CINB, i = idx - j * CINB;
-            if (j < Cout && i < nci) slab[(int64_t)j * Cin + c0 + i] = s;
+            if (j < Cout && i < nci) slab[(int64_t)j * Cin + c0 + i] = sv;
         } else {
             int j = idx - NCO * CINB;
-            if (j < Cout && blockIdx.y == 0) slab[nW + j] = s;
+            if (j < Cout && blockIdx.z == 0) slab[nW + j] = sv;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------- seg loss
-// per-voxel softmax helpers (C <= MAXC, fully unrolled with predicates)
-__device__ __forceinline__ void softmax_c(const float (&z)[MAXC], int C, float inv_t, float (&p)[MAXC], float& lse) {
+// per-voxel softmax helpers (C <= NC, fully unrolled with predicates)
+template <int NC>
+__device__ __forceinline__ void softmax_c(const float (&z)[NC], int C, float inv_t, float (&p)[NC], float& lse) {
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) if (c < C) mx = fmaxf(mx, z[c] * inv_t);
+    for (int c = 0; c < NC; c++) if (c < C) mx = fmaxf(mx, z[c] * inv_t);
     float se = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) { p[c] = c < C ? __expf(z[c] * inv_t - mx) : 0.f; se += p[c]; }
+    for (int c = 0; c < NC; c++) { p[c] = c < C ? __expf(z[c] * inv_t - mx) : 0.f; se += p[c]; }
     float r = 1.f / se;
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) p[c] *= r;
+    for (int c = 0; c < NC; c++) p[c] *= r;
     lse = mx + __logf(se);
+}
+
+// VV consecutive voxels of one sample: class planes as 16-byte loads (VV = 4) -- grid = (blocks, N), no per-voxel
+// 64-bit division
+template <int NC, int VV>
+__device__ __forceinline__ void load_planes(const float* __restrict__ base, int C, int64_t V, int64_t v0, float (&z)[VV][NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (c < C) {
+            if constexpr (VV == 4) {
+                float4 t = *reinterpret_cast<const float4*>(base + (int64_t)c * V + v0);
+                z[0][c] = t.x; z[1][c] = t.y; z[2][c] = t.z; z[3][c] = t.w;
+            } else z[0][c] = base[(int64_t)c * V + v0];
+        } else {
+#pragma unroll
+            for (int k = 0; k < VV; k++) z[k][c] = 0.f;
+        }
+    }
+}
+template <int VV>
+__device__ __forceinline__ void load_labels(const int64_t* __restrict__ lb, int (&t)[VV]) {
+    if constexpr (VV == 4) {
+        longlong2 a = *reinterpret_cast<const longlong2*>(lb), b = *reinterpret_cast<const longlong2*>(lb + 2);
+        t[0] = (int)a.x; t[1] = (int)a.y; t[2] = (int)b.x; t[3] = (int)b.y;
+    } else t[0] = (int)lb[0];
 }
 
 constexpr int NQ = 2 + 3 * MAXC;   // ce, kl, I[c], P[c], T[c]
 
+template <int NC, int VV>
 __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ teacher, int N, int C, int64_t V,
+                                                           const float* __restrict__ teacher, int C, int64_t V,
                                                            float inv_t, double* __restrict__ part) {
-    __shared__ float red[4][NQ];
-    int64_t M = (int64_t)N * V;
-    float q[NQ];
+    constexpr int NQL = 2 + 3 * NC;
+    __shared__ float red[4][NQL];
+    int n = blockIdx.y;
+    const float* lg = logits + (int64_t)n * C * V;
+    const float* tg = teacher ? teacher + (int64_t)n * C * V : nullptr;
+    const int64_t* lb = labels + (int64_t)n * V;
+    float q[NQL];
 #pragma unroll
-    for (int i = 0; i < NQ; i++) q[i] = 0.f;
-    for (int64_t m = (int64_t)blockIdx.x * BLK + threadIdx.x; m < M; m += (int64_t)gridDim.x * BLK) {
-        int64_t n = m / V, v = m - n * V;
-        float z[MAXC], p[MAXC], lse;
+    for (int i = 0; i < NQL; i++) q[i] = 0.f;
+    int64_t ngrp = V / VV;
+    for (int64_t grp = (int64_t)blockIdx.x * BLK + threadIdx.x; grp < ngrp; grp += (int64_t)gridDim.x * BLK) {
+        int64_t v0 = grp * VV;
+        float z[VV][NC];
+        int t[VV];
+        load_planes<NC, VV>(lg, C, V, v0, z);
+        load_labels<VV>(lb + v0, t);
+        float zt_[VV][NC];
+        if (tg) load_planes<NC, VV>(tg, C, V, v0, zt_);
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) z[c] = c < C ? logits[((int64_t)n * C + c) * V + v] : 0.f;
-        int t = (int)labels[m];
-        softmax_c(z, C, 1.f, p, lse);
-        float zt = 0.f;
+        for (int k = 0; k < VV; k++) {
+            float p[NC], lse;
+            softmax_c<NC>(z[k], C, 1.f, p, lse);
+            float zt = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) {
-            if (c < C) {
-                bool is = (c == t);
-                zt = is ? z[c] : zt;
-                q[2 + c] += is ? p[c] : 0.f;
-                q[2 + MAXC + c] += p[c];
-                q[2 + 2 * MAXC + c] += is ? 1.f : 0.f;
+            for (int c = 0; c < NC; c++) {
+                if (c < C) {
+                    bool is = (c == t[k]);
+                    zt = is ? z[k][c] : zt;
+                    q[2 + c] += is ? p[c] : 0.f;
+                    q[2 + NC + c] += p[c];
+                    q[2 + 2 * NC + c] += is ? 1.f : 0.f;
+                }
             }
-        }
-        q[0] += lse - zt;
-        if (teacher) {
-            float zt_[MAXC], ps[MAXC], pt[MAXC], ls, lt;
+            q[0] += lse - zt;
+            if (tg) {
+                float ps[NC], pt[NC], ls, lt;
+                softmax_c<NC>(z[k], C, inv_t, ps, ls);
+                softmax_c<NC>(zt_[k], C, inv_t, pt, lt);
+                float kl = 0.f;
 #pragma unroll
-            for (int c = 0; c < MAXC; c++) zt_[c] = c < C ? teacher[((int64_t)n * C + c) * V + v] : 0.f;
-            softmax_c(z, C, inv_t, ps, ls);
-            softmax_c(zt_, C, inv_t, pt, lt);
-            float kl = 0.f;
-#pragma unroll
-            for (int c = 0; c < MAXC; c++)
-                if (c < C && pt[c] > 0.f) kl += pt[c] * ((zt_[c] * inv_t - lt) - (z[c] * inv_t - ls));
-            q[1] += kl;
+                for (int c = 0; c < NC; c++)
+                    if (c < C && pt[c] > 0.f) kl += pt[c] * ((zt_[k][c] * inv_t - lt) - (z[k][c] * inv_t - ls));
+                q[1] += kl;
+            }
         }
     }
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        float s = wave_sum(q[i]);
-        if (lane == 0) red[wave][i] = s;
+    for (int i = 0; i < NQL; i++) {
+        float sv = wave_sum(q[i]);
+        if (lane == 0) red[wave][i] = sv;
     }
     __syncthreads();
-    if (threadIdx.x < NQ)
-        part[(int64_t)blockIdx.x * NQ + threadIdx.x] =
-            (double)red[0][threadIdx.x] + (double)red[1][threadIdx.x] + (double)red[2][threadIdx.x] + (double)red[3][threadIdx.x];
+    if (threadIdx.x < NQ) {                                    // partial row in the MAXC layout the finalize reads
+        int i = threadIdx.x, src = -1;
+        if (i < 2) src = i;
+        else { int k = (i - 2) / MAXC, c = (i - 2) % MAXC; if (c < NC) src = 2 + k * NC + c; }
+        double v = 0.0;
+        if (src >= 0) v = (double)red[0][src] + (double)red[1][src] + (double)red[2][src] + (double)red[3][src];
+        part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NQ + i] = v;
+    }
 }
 
 // one 1024-thread block: wave w sums quantities w, w+16 over the block partials (lane-strided doubles + wave tree:
@@ -258,93 +329,117 @@ __global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* _
     }
 }
 
+template <int NC, int VV>
 __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ teacher, int N, int C, int64_t V,
+                                                           const float* __restrict__ teacher, int C, int64_t V,
                                                            float inv_t, const float* __restrict__ coef,
                                                            const float* __restrict__ grad_out, float* __restrict__ dlogits) {
-    int64_t M = (int64_t)N * V;
+    int n = blockIdx.y;
+    const float* lg = logits + (int64_t)n * C * V;
+    const float* tg = teacher ? teacher + (int64_t)n * C * V : nullptr;
+    const int64_t* lb = labels + (int64_t)n * V;
+    float* dg = dlogits + (int64_t)n * C * V;
     float go = grad_out ? grad_out[0] : 1.f;
-    float A[MAXC], B[MAXC];
+    float A[NC], B[NC];
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) { A[c] = coef[c]; B[c] = coef[MAXC + c]; }
+    for (int c = 0; c < NC; c++) { A[c] = coef[c]; B[c] = coef[MAXC + c]; }
     float ce_s = coef[2 * MAXC], kd_s = coef[2 * MAXC + 1];
-    for (int64_t m = (int64_t)blockIdx.x * BLK + threadIdx.x; m < M; m += (int64_t)gridDim.x * BLK) {
-        int64_t n = m / V, v = m - n * V;
-        float z[MAXC], p[MAXC], g[MAXC], lse;
+    int64_t ngrp = V / VV;
+    for (int64_t grp = (int64_t)blockIdx.x * BLK + threadIdx.x; grp < ngrp; grp += (int64_t)gridDim.x * BLK) {
+        int64_t v0 = grp * VV;
+        float z[VV][NC], o[VV][NC];
+        int t[VV];
+        load_planes<NC, VV>(lg, C, V, v0, z);
+        load_labels<VV>(lb + v0, t);
+        float zt_[VV][NC];
+        if (tg) load_planes<NC, VV>(tg, C, V, v0, zt_);
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) z[c] = c < C ? logits[((int64_t)n * C + c) * V + v] : 0.f;
-        int t = (int)labels[m];
-        softmax_c(z, C, 1.f, p, lse);
-        float dot = 0.f;
+        for (int k = 0; k < VV; k++) {
+            float p[NC], g[NC], lse;
+            softmax_c<NC>(z[k], C, 1.f, p, lse);
+            float dot = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) {
-            g[c] = (c == t ? A[c] : 0.f) + B[c];
-            dot += g[c] * p[c];
+            for (int c = 0; c < NC; c++) {
+                g[c] = (c == t[k] ? A[c] : 0.f) + B[c];
+                dot += g[c] * p[c];
+            }
+            float kd[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) kd[c] = 0.f;
+            if (tg) {
+                float ps[NC], pt[NC], ls, lt;
+                softmax_c<NC>(z[k], C, inv_t, ps, ls);
+                softmax_c<NC>(zt_[k], C, inv_t, pt, lt);
+#pragma unroll
+                for (int c = 0; c < NC; c++) kd[c] = kd_s * (ps[c] - pt[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) o[k][c] = go * (ce_s * (p[c] - (c == t[k] ? 1.f : 0.f)) + p[c] * (g[c] - dot) + kd[c]);
         }
-        float kd[MAXC];
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) kd[c] = 0.f;
-        if (teacher) {
-            float zt_[MAXC], ps[MAXC], pt[MAXC], ls, lt;
-#pragma unroll
-            for (int c = 0; c < MAXC; c++) zt_[c] = c < C ? teacher[((int64_t)n * C + c) * V + v] : 0.f;
-            softmax_c(z, C, inv_t, ps, ls);
-            softmax_c(zt_, C, inv_t, pt, lt);
-#pragma unroll
-            for (int c = 0; c < MAXC; c++) kd[c] = kd_s * (ps[c] - pt[c]);
+        for (int c = 0; c < NC; c++) {
+            if (c < C) {
+                if constexpr (VV == 4) *reinterpret_cast<float4*>(dg + (int64_t)c * V + v0) = float4{o[0][c], o[1][c], o[2][c], o[3][c]};
+                else dg[(int64_t)c * V + v0] = o[0][c];
+            }
         }
-#pragma unroll
-        for (int c = 0; c < MAXC; c++)
-            if (c < C)
-                dlogits[((int64_t)n * C + c) * V + v] = go * (ce_s * (p[c] - (c == t ? 1.f : 0.f)) + p[c] * (g[c] - dot) + kd[c]);
     }
 }
 
 // ------------------------------------------------------------------------------------------ metrics
+template <int NC, int VV>
 __global__ __launch_bounds__(BLK) void seg_metrics_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                          int N, int C, int64_t V, unsigned long long* __restrict__ counts) {
+                                                          int C, int64_t V, unsigned long long* __restrict__ counts) {
     // counts: [0..C) n_inter, [MAXC..) n_pred, [2*MAXC..) n_tgt, [3*MAXC] n_correct
-    int64_t M = (int64_t)N * V;
-    unsigned ni[MAXC], np[MAXC], nt[MAXC], nc = 0;
+    int n = blockIdx.y;
+    const float* lg = logits + (int64_t)n * C * V;
+    const int64_t* lb = labels + (int64_t)n * V;
+    unsigned ni[NC], np[NC], nt[NC], nc = 0;
 #pragma unroll
-    for (int c = 0; c < MAXC; c++) ni[c] = np[c] = nt[c] = 0;
-    int64_t start = (int64_t)blockIdx.x * BLK, stride = (int64_t)gridDim.x * BLK;
-    for (int64_t base = start; base < M; base += stride) {     // wave-uniform trip count for the ballots
-        int64_t m = base + threadIdx.x;
-        bool ok = m < M;
-        int best = -1, t = -2;
-        if (ok) {
-            int64_t n = m / V, v = m - n * V;
-            float bv = logits[((int64_t)n * C) * V + v];
-            best = 0;
-            for (int c = 1; c < C; c++) {
-                float zc = logits[((int64_t)n * C + c) * V + v];
-                if (zc > bv) { bv = zc; best = c; }
+    for (int c = 0; c < NC; c++) ni[c] = np[c] = nt[c] = 0;
+    int64_t ngrp = V / VV;
+    for (int64_t grp = (int64_t)blockIdx.x * BLK + threadIdx.x; grp < ngrp; grp += (int64_t)gridDim.x * BLK) {
+        int64_t v0 = grp * VV;
+        float z[VV][NC];
+        int t[VV];
+        load_planes<NC, VV>(lg, C, V, v0, z);
+        load_labels<VV>(lb + v0, t);
+#pragma unroll
+        for (int k = 0; k < VV; k++) {
+            float bv = z[k][0];
+            int best = 0;
+#pragma unroll
+            for (int c = 1; c < NC; c++)
+                if (c < C && z[k][c] > bv) { bv = z[k][c]; best = c; }       // first maximum wins, as torch.argmax
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                ni[c] += (best == c && t[k] == c) ? 1u : 0u;
+                np[c] += (best == c) ? 1u : 0u;
+                nt[c] += (t[k] == c) ? 1u : 0u;
             }
-            t = (int)labels[m];
+            nc += (best == t[k]) ? 1u : 0u;
         }
-#pragma unroll
-        for (int c = 0; c < MAXC; c++) {
-            if (c < C) {
-                ni[c] += __popcll(__ballot(best == c && t == c));
-                np[c] += __popcll(__ballot(best == c));
-                nt[c] += __popcll(__ballot(t == c));
-            }
-        }
-        nc += __popcll(__ballot(ok && best == t));
     }
-    // per-wave counts -> LDS -> one partial row per block (exact integers, no atomics)
-    __shared__ unsigned red[4][3 * MAXC + 1];
-    int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    // per-thread counts -> wave sums -> LDS -> one partial row per block (exact integers, no atomics)
+    __shared__ unsigned red[4][3 * NC + 1];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    auto wsum = [&](unsigned v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
 #pragma unroll
-        for (int c = 0; c < MAXC; c++) { red[wave][c] = ni[c]; red[wave][MAXC + c] = np[c]; red[wave][2 * MAXC + c] = nt[c]; }
-        red[wave][3 * MAXC] = nc;
+    for (int c = 0; c < NC; c++) {
+        unsigned a = wsum(ni[c]), b = wsum(np[c]), d = wsum(nt[c]);
+        if (lane == 0) { red[wave][c] = a; red[wave][NC + c] = b; red[wave][2 * NC + c] = d; }
     }
+    unsigned e = wsum(nc);
+    if (lane == 0) red[wave][3 * NC] = e;
     __syncthreads();
-    if (threadIdx.x < 3 * MAXC + 1)
-        counts[(int64_t)blockIdx.x * (3 * MAXC + 1) + threadIdx.x] =
-            (unsigned long long)red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 3 * MAXC + 1) {
+        int i = threadIdx.x, src = -1;
+        if (i == 3 * MAXC) src = 3 * NC;
+        else { int k = i / MAXC, c = i % MAXC; if (c < NC) src = k * NC + c; }
+        unsigned long long v = 0;
+        if (src >= 0) v = (unsigned long long)red[0][src] + red[1][src] + red[2][src] + red[3][src];
+        counts[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (3 * MAXC + 1) + i] = v;
+    }
 }
 
 // Q1: the reference's class loop is range(1, pred.size(1)) AFTER argmax -> bound = first spatial dim D
@@ -387,15 +482,31 @@ inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 constexpr int CONV1_NBLK = 512;
 }  // namespace
 
+// blocks per sample for the (blocks, N) grids: `cap` blocks in total, at least one per sample
+inline int per_sample_blocks(int64_t V, int vv, int N, int cap) {
+    int64_t w = (V / vv + BLK - 1) / BLK, c = cap / N;
+    if (c < 1) c = 1;
+    return (int)(w < 1 ? 1 : (w > c ? c : w));
+}
+inline bool vv4(int64_t V, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return V % 4 == 0 && al16(a) && al16(b) && al16(c);
+}
+
 int conv1_fwd(int dtype, const void* z, int zcs, int Cin, const float* w, const float* bias, float* logits, int Cout,
               int N, int64_t V, hipStream_t s) {
     MI3D_CHECK_ARG(Cin >= 1 && Cout >= 1, "conv1_fwd: bad channels");
-    dim3 grid((unsigned)sgrid((int64_t)N * V, 4096), (unsigned)cdiv(Cout, MAXC));
     DISPATCH_T(dtype, T, {
-        if (Cin % CINB == 0 && zcs % 8 == 0 && al16(z))
-            conv1_fwd_kernel<T, true><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, bias, logits, Cout, N, V);
-        else
-            conv1_fwd_kernel<T, false><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, bias, logits, Cout, N, V);
+        bool vec = Cin % CINB == 0 && zcs % 8 == 0 && al16(z);
+        // one voxel per thread: consecutive lanes read consecutive 32-byte channel rows (a thread owning 4 voxels would
+        // spread every 16-byte load instruction of a wave over 64 cache lines -- measured 1.7x slower)
+        if (vec && Cout <= 4) {
+            dim3 grid((unsigned)per_sample_blocks(V, 1, N, 4096), (unsigned)N, 1);
+            conv1_fwd_kernel<T, true, 4, 1><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, bias, logits, Cout, V);
+        } else {
+            dim3 grid((unsigned)per_sample_blocks(V, 1, N, 4096), (unsigned)N, (unsigned)cdiv(Cout, MAXC));
+            if (vec) conv1_fwd_kernel<T, true, MAXC, 1><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, bias, logits, Cout, V);
+            else conv1_fwd_kernel<T, false, MAXC, 1><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, bias, logits, Cout, V);
+        }
         MI3D_LAUNCH_CHECK();
     });
     return 0;
@@ -406,19 +517,24 @@ size_t conv1_bwd_ws_floats(int Cin, int Cout) { return (size_t)CONV1_NBLK * ((si
 int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const float* dlogits, int Cout, void* dz,
               int dzcs, float* dW, float* db, int accumulate, float* ws, int N, int64_t V, hipStream_t s) {
     MI3D_CHECK_ARG(Cout <= MAXC, "conv1_bwd: out_channels %d > %d unsupported", Cout, MAXC);
-    int nblk = sgrid((int64_t)N * V, CONV1_NBLK);
+    MI3D_CHECK_ARG(N <= CONV1_NBLK, "conv1_bwd: batch %d > %d unsupported", N, CONV1_NBLK);
     int64_t nW = (int64_t)Cin * Cout;
-    // every slab element is written by exactly one (blockIdx.x, blockIdx.y) block
-    dim3 grid((unsigned)nblk, (unsigned)cdiv(Cin, CINB));
+    int nslab = 0;
+    // every slab element is written by exactly one (blockIdx.x, blockIdx.y, blockIdx.z) block
     DISPATCH_T(dtype, T, {
         bool vec = Cin % CINB == 0 && zcs % 8 == 0 && al16(z) && (!dz || (dzcs % 8 == 0 && al16(dz)));
-if (vec && Cout <= 4) conv1_bwd_kernel<T, true, 4><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
-        else if (vec) conv1_bwd_kernel<T, true, MAXC><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
-        else if (Cout <= 4) conv1_bwd_kernel<T, false, 4><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
-        else conv1_bwd_kernel<T, false, MAXC><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, N, V, ws);
+        bool v4 = false;        // see conv1_fwd: one voxel per thread keeps the channel-row loads coalesced
+        int bx = per_sample_blocks(V, v4 ? 4 : 1, N, CONV1_NBLK);
+        nslab = bx * N;
+        dim3 grid((unsigned)bx, (unsigned)N, (unsigned)cdiv(Cin, CINB));
+        if (v4) conv1_bwd_kernel<T, true, 4, 4><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, V, ws);
+        else if (vec && Cout <= 4) conv1_bwd_kernel<T, true, 4, 1><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, V, ws);
+        else if (vec) conv1_bwd_kernel<T, true, MAXC, 1><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, V, ws);
+        else if (Cout <= 4) conv1_bwd_kernel<T, false, 4, 1><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, V, ws);
+        else conv1_bwd_kernel<T, false, MAXC, 1><<<grid, BLK, 0, s>>>((const T*)z, zcs, Cin, w, dlogits, Cout, (T*)dz, dzcs, V, ws);
         MI3D_LAUNCH_CHECK();
     });
-    return slab_reduce(ws, nblk, nW + Cout, nW, dW, db, accumulate, s);
+    return slab_reduce(ws, nslab, nW + Cout, nW, dW, db, accumulate, s);
 }
 
 size_t seg_loss_ws_bytes(int C) { return (size_t)LOSS_MAXBLK * NQ * sizeof(double); }
@@ -427,11 +543,18 @@ int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teache
                  float* loss_out, float* coef, void* ws, hipStream_t s) {
     MI3D_CHECK_ARG(C >= 1 && C <= MAXC, "seg_loss: %d classes unsupported (max %d)", C, MAXC);
     MI3D_CHECK_ARG(cfg.w_kd == 0.f || teacher, "seg_loss: distillation weight without teacher logits");
-    int nblk = sgrid((int64_t)N * V / 4, LOSS_MAXBLK);
+    MI3D_CHECK_ARG(N <= LOSS_MAXBLK, "seg_loss: batch %d > %d unsupported", N, LOSS_MAXBLK);
     const float* tch = cfg.w_kd != 0.f ? teacher : nullptr;
-    seg_loss_fwd_kernel<<<nblk, BLK, 0, s>>>(logits, labels, tch, N, C, V, 1.f / cfg.temp, (double*)ws);
+    bool v4 = vv4(V, logits, labels, tch);
+    int bx = per_sample_blocks(V, v4 ? 4 : 1, N, LOSS_MAXBLK);
+    dim3 grid((unsigned)bx, (unsigned)N);
+    float it = 1.f / cfg.temp;
+    if (C <= 4 && v4) seg_loss_fwd_kernel<4, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
+    else if (C <= 4) seg_loss_fwd_kernel<4, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
+    else if (v4) seg_loss_fwd_kernel<MAXC, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
+    else seg_loss_fwd_kernel<MAXC, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
     MI3D_LAUNCH_CHECK();
-    seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, nblk, N, C, V, cfg, loss_out, coef);
+    seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, bx * N, N, C, V, cfg, loss_out, coef);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -440,8 +563,13 @@ int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teache
                  const float* coef, const float* grad_out, float* dlogits, hipStream_t s) {
     MI3D_CHECK_ARG(C >= 1 && C <= MAXC, "seg_loss_bwd: %d classes unsupported", C);
     const float* tch = cfg.w_kd != 0.f ? teacher : nullptr;
-    seg_loss_bwd_kernel<<<sgrid((int64_t)N * V, 4096), BLK, 0, s>>>(logits, labels, tch, N, C, V, 1.f / cfg.temp, coef,
-                                                                    grad_out, dlogits);
+    bool v4 = vv4(V, logits, labels, tch) && al16(dlogits);
+    dim3 grid((unsigned)per_sample_blocks(V, v4 ? 4 : 1, N, 4096), (unsigned)N);
+    float it = 1.f / cfg.temp;
+    if (C <= 4 && v4) seg_loss_bwd_kernel<4, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
+    else if (C <= 4) seg_loss_bwd_kernel<4, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
+    else if (v4) seg_loss_bwd_kernel<MAXC, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
+    else seg_loss_bwd_kernel<MAXC, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -451,10 +579,17 @@ size_t seg_metrics_ws_bytes(int C) { return (size_t)METRIC_BLOCKS * (3 * MAXC + 
 int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out, void* ws,
                 hipStream_t s) {
     MI3D_CHECK_ARG(C >= 1 && C <= MAXC, "seg_metrics: %d classes unsupported", C);
-    int nblk = sgrid((int64_t)N * V / 8, METRIC_BLOCKS);
-    seg_metrics_kernel<<<nblk, BLK, 0, s>>>(logits, labels, N, C, V, (unsigned long long*)ws);
+    MI3D_CHECK_ARG(N <= METRIC_BLOCKS, "seg_metrics: batch %d > %d unsupported", N, METRIC_BLOCKS);
+    bool v4 = vv4(V, logits, labels);
+    int bx = per_sample_blocks(V, v4 ? 4 : 1, N, METRIC_BLOCKS);
+    dim3 grid((unsigned)bx, (unsigned)N);
+    unsigned long long* cw = (unsigned long long*)ws;
+    if (C <= 4 && v4) seg_metrics_kernel<4, 4><<<grid, BLK, 0, s>>>(logits, labels, C, V, cw);
+    else if (C <= 4) seg_metrics_kernel<4, 1><<<grid, BLK, 0, s>>>(logits, labels, C, V, cw);
+    else if (v4) seg_metrics_kernel<MAXC, 4><<<grid, BLK, 0, s>>>(logits, labels, C, V, cw);
+    else seg_metrics_kernel<MAXC, 1><<<grid, BLK, 0, s>>>(logits, labels, C, V, cw);
     MI3D_LAUNCH_CHECK();
-    seg_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const unsigned long long*)ws, nblk, N, C, D, V, out);
+    seg_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const unsigned long long*)ws, bx * N, N, C, D, V, out);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

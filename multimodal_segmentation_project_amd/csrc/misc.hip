@@ -23,19 +23,26 @@ inline int sgrid(int64_t total, int cap = 2048) {
     return (int)(w < 1 ? 1 : (w > cap ? cap : w));
 }
 
-// fixed-order parallel slab sum: block = 32 elements x 8 slab groups (each thread sums every 8th slab, then a tree)
+// fixed-order parallel slab sum: block = EW elements x 256/EW slab groups (each thread sums every SG-th slab, then a
+// tree).  EW = 4 for tiny slabs (1x1x1 head: 68 floats x 512 slabs) so the parallelism comes from the slab dimension.
+template <int EW>
 __global__ __launch_bounds__(BLK) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz, int64_t nW,
                                                           float* __restrict__ dW, float* __restrict__ db, int accumulate) {
-    __shared__ float red[8][32];
-    int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    int64_t i = (int64_t)blockIdx.x * 32 + e;
+    constexpr int SG = BLK / EW;
+    __shared__ float red[SG][EW];
+    int e = threadIdx.x % EW, sg = threadIdx.x / EW;
+    int64_t i = (int64_t)blockIdx.x * EW + e;
     float s = 0.f;
     if (i < slab_sz)
-        for (int b = sg; b < nslab; b += 8) s += slabs[(int64_t)b * slab_sz + i];
+        for (int b = sg; b < nslab; b += SG) s += slabs[(int64_t)b * slab_sz + i];
     red[sg][e] = s;
     __syncthreads();
     if (sg == 0 && i < slab_sz) {
-        float t = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) + ((red[4][e] + red[5][e]) + (red[6][e] + red[7][e]));
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < SG; k += 8)
+            t += ((red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e])) +
+                 ((red[k + 4][e] + red[k + 5][e]) + (red[k + 6][e] + red[k + 7][e]));
         if (i < nW) { if (dW) dW[i] = accumulate ? dW[i] + t : t; }
         else if (db) { db[i - nW] = accumulate ? db[i - nW] + t : t; }
     }
@@ -205,7 +212,9 @@ __global__ void scale_add_kernel(float* dst, const float* src, int64_t n, float 
 
 int slab_reduce(const float* slabs, int nslab, int64_t slab_sz, int64_t nW, float* dW, float* db, int accumulate,
                 hipStream_t s) {
-    slab_reduce_kernel<<<cdiv(slab_sz, 32), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
+    if (slab_sz < 1024) slab_reduce_kernel<4><<<cdiv(slab_sz, 4), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
+    else if (slab_sz < (16 << 10)) slab_reduce_kernel<8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
+    else slab_reduce_kernel<32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
