@@ -69,6 +69,38 @@ __global__ __launch_bounds__(BLK) void bn_stats_kernel(const T* __restrict__ y, 
     block_colreduce<VEC, 2>(acc, C, active, lds, part);
 }
 
+// split-K convolutions (deep levels): the finishing pass y = bf16(bias + sum_k part[k]) runs HERE, fused with the
+// statistics of the rounded values it stores -- one launch and one read of y less per layer
+__global__ __launch_bounds__(BLK) void bn_stats_splitk_kernel(const float* __restrict__ skp, int ks, const float* __restrict__ bias,
+                                                              bf16* __restrict__ y, int ycs, int C, int64_t M,
+                                                              float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int r, g, R;
+    bool active = row_map<8>(C, r, g, R);
+    float acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[0][i] = acc[1][i] = 0.f;
+    if (active) {
+        float bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) bv[i] = bias ? bias[g * 8 + i] : 0.f;
+        for (int64_t row = (int64_t)blockIdx.x * R + r; row < M; row += (int64_t)gridDim.x * R) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = bv[i];
+            for (int k = 0; k < ks; k++) {
+                const float* p = skp + ((int64_t)k * M + row) * C + g * 8;
+                float4 u = *reinterpret_cast<const float4*>(p), w = *reinterpret_cast<const float4*>(p + 4);
+                v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w; v[4] += w.x; v[5] += w.y; v[6] += w.z; v[7] += w.w;
+            }
+            st8<bf16>(y + row * ycs + g * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { float q = (float)(bf16)v[i]; acc[0][i] += q; acc[1][i] += q * q; }
+        }
+    }
+    block_colreduce<8, 2>(acc, C, active, lds, part);
+}
+
 // one 64-lane block per channel: double sums of the partials in a fixed order
 __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
                                          const float* gamma, const float* beta, float* running_mean,
@@ -326,5 +358,21 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
             bn_bwd_apply_kernel<T, 1><<<stream_grid(M * C, C), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
         MI3D_LAUNCH_CHECK();
     });
+    return 0;
+}
+
+int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, int ycs, int C, int64_t M, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                          float* stat, float* ws, hipStream_t s) {
+    MI3D_CHECK_ARG(C % 8 == 0 && C / 8 <= BLK && ycs % 8 == 0 && ((uintptr_t)y % 16 == 0) && ks >= 1 && M >= 1,
+                   "bn_train_stats_splitk: unsupported shape C=%d ycs=%d", C, ycs);
+    int G = C / 8, R = BLK / G;
+    int64_t want = (M + R - 1) / R;                 // one row per thread: the ks fp32 partial reads dominate, spread them wide
+    int nblk = (int)(want > MAXBLK ? MAXBLK : want);
+    size_t lds = (size_t)2 * R * C * sizeof(float);
+    bn_stats_splitk_kernel<<<nblk, BLK, lds, s>>>(skp, ks, bias, (bf16*)y, ycs, C, M, ws);
+    MI3D_LAUNCH_CHECK();
+    bn_stats_finalize_kernel<<<C, 64, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
+    MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -595,13 +595,14 @@ __global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restr
 
 template <int TZ, int TYB, int TXB, int BX, int COB>
 int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bias, bf16* y, int ycs, int Cout, Geo g,
-               float* part, int ksplit, float* skws, hipStream_t s) {
+               float* part, int ksplit, float* skws, hipStream_t s, bool defer_finish = false) {
     constexpr int TY = TYB * (16 / BX), TX = TXB * BX;
     int tz = cdiv(g.D, TZ), ty = cdiv(g.H, TY), tx = cdiv(g.W, TX);
     dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)), (unsigned)ksplit);
     if (ksplit > 1) {
         conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, nullptr, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, skws);
         MI3D_LAUNCH_CHECK();
+        if (defer_finish) return 0;
         int64_t tot = g.M() * (Cout / 8);
         splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ksplit, g.M(), Cout, bias, y, ycs);
     } else if (part)
@@ -685,7 +686,8 @@ bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g) { return pick_ksplit(Cin, 
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g) { return persist_ok(Cin, Cout, g); }
 
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
-                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh) {
+                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred) {
+    if (ks_deferred) *ks_deferred = 0;
     MI3D_CHECK_ARG((!xh.on() && !yh.on()) || persist_ok(Cin, Cout, g), "conv3_mfma_fwd: planar halves need the persistent kernel");
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, ycs), "conv3_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
     MI3D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, "conv3_mfma_fwd: misaligned tensors");
@@ -711,8 +713,10 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s);
         return launch_cfg<4, 8, 1, 16, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s);
     }
-    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s);
-    return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s);
+    bool defer = ks > 1 && ks_deferred;
+    if (defer) *ks_deferred = ks;
+    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer);
+    return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer);
 }
 
 // =================================================================================================== wgrad

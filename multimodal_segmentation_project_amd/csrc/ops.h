@@ -47,7 +47,10 @@ bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g);        // false -> caller
 struct Halves { int split = 1 << 30; int64_t delta = 0; bool on() const { return delta != 0; } };
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g);          // forward (Cin,Cout) launch can take Halves x / y
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
-                   Geo g, float* part, float* skws, hipStream_t s, Halves xh = Halves(), Halves yh = Halves());
+                   Geo g, float* part, float* skws, hipStream_t s, Halves xh = Halves(), Halves yh = Halves(),
+                   int* ks_deferred = nullptr);
+// ks_deferred != NULL: a split-K launch leaves its fp32 partials in skws ([ks][M][Cout]) WITHOUT the finishing pass and
+// reports ks there (0 = y was written as usual); the caller finishes (bn_train_stats_splitk, fused with the statistics)
 
 size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
@@ -76,6 +79,11 @@ int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int6
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
            int accumulate, float* ws, hipStream_t s);
+
+// split-K conv finish (y = bf16(bias + sum_k skp[k][M][C])) fused with the batch statistics of the stored values
+int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, int ycs, int C, int64_t M, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          float momentum, float eps, float* stat, float* ws, hipStream_t s);
 
 // ---- MaxPool3d(2,2) ------------------------------------------------------------------------ pool.hip
 // Reference: models/unet.py:40,71.  g = INPUT geometry (even D,H,W required).

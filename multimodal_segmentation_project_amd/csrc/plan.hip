@@ -218,11 +218,15 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         float* rv = buffers ? (float*)buffers[H.bidx + 1] : nullptr;
         int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
         bool fused_stats = false;
+        void* zo = h == 0 ? c.at(B.z1) : zout;
+        int zocs = h == 0 ? H.Cout : zcs;
+        int ksd = 0;
         if (H.mfma) {
             if (!c.packed) MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
+            // training: a split-K launch leaves its finishing pass to the statistics kernel (ksd = split factor)
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
                                     training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
-                                    (h == 0 && b > p.L) ? p.halves(B.level) : Halves()));
+                                    (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr));
             fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
         } else {
             MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), c.at<float>(H.wpd), c.s));
@@ -232,6 +236,10 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         if (fused_stats) {
             MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
                                        c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.s));
+        } else if (training && ksd > 0) {
+            MI3D_TRY(bn_train_stats_splitk(c.at<float>(p.skws), ksd, c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2),
+                                           c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat),
+                                           c.at<float>(p.bnws), c.s));
         } else if (training) {
             MI3D_TRY(bn_train_stats(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt,
                                     p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.at<float>(p.bnws), c.s));
@@ -239,8 +247,6 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             MI3D_CHECK_ARG(rm && rv, "eval-mode forward needs running statistics");
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
-        void* zo = h == 0 ? c.at(B.z1) : zout;
-        int zocs = h == 0 ? H.Cout : zcs;
         MI3D_TRY(bn_apply_relu_drop(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
                                     (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, c.s));
     }
