@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.0, help="run_training.sh:31 ships --dropout_rate 0.0")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--two-stream", action="store_true", help="weight gradients on a second stream beside the data-gradient chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3 --pmc passes)")
@@ -153,7 +154,7 @@ def main():
     model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=a.dropout).to(dev).train()
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt,
-                   use_graph=(world == 1 and not a.no_graph))
+                   use_graph=(world == 1 and not a.no_graph), two_stream=a.two_stream)
     x, y = synth(a.batch, a.size, 1234 + rank)
     ts.load_batch(x.to(dev), y.to(dev))
 

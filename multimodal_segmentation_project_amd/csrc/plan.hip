@@ -179,6 +179,7 @@ struct Ctx {
     hipStream_t s2 = nullptr;
     hipEvent_t* ev = nullptr;
     mutable int seq = 0;
+    mutable bool rec[2] = {false, false};       // done-events recorded by this call (aux-stream wgrads in flight)
     mutable bool packed = false;      // weight packs already done by the one-launch pack_all
     template <typename T = void> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
     const float* P(int i) const { return reinterpret_cast<const float*>(params[i]); }
@@ -262,12 +263,13 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
     const void* xin; int xcs, xdt;
     block_input(c, b, x, xin, xcs, xdt);
     auto G = [&](int i) { return grads ? (float*)grads[i] : nullptr; };
+    // measured (96^3, hipGraph): any second stream in the captured graph costs ~130 us/step more than it hides -> off by default
     bool two = c.s2 != nullptr && c.ev != nullptr;
     for (int h = 1; h >= 0; h--) {
         const HalfP& H = B.h[h];
         int k = c.seq++;
         void* dyb = c.at((k & 1) ? p.sB2 : p.sB);            // dy ping-pong: the aux-stream wgrad may still read the other one
-        if (two && k >= 2) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + (k & 1)], 0));
+        if (c.rec[k & 1]) { MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + (k & 1)], 0)); c.rec[k & 1] = false; }
         const void* dz = h == 1 ? dz2 : c.at(p.sC);
         int dcs = h == 1 ? dzcs : H.Cout;
         MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
@@ -293,7 +295,7 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             else
                 MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
                                             accumulate, wgws, p.wgws_floats, ws_));
-            if (two) MI3D_HIP(hipEventRecord(c.ev[2 + (k & 1)], c.s2));
+            if (two) { MI3D_HIP(hipEventRecord(c.ev[2 + (k & 1)], c.s2)); c.rec[k & 1] = true; }
         }
         void* dx = h == 1 ? c.at(p.sC) : dxin;
         int dxs = h == 1 ? H.Cin : dxcs;
@@ -453,10 +455,8 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
         }
     }
     // join: everything the aux stream produced is ordered before whatever the caller enqueues next on `stream`
-    if (c.s2 && c.seq > 0) {
-        MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2], 0));
-        if (c.seq > 1) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[3], 0));
-    }
+    for (int i = 0; i < 2; i++)
+        if (c.rec[i]) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + i], 0));
     return 0;
 }
 
