@@ -369,6 +369,18 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
         rel[it] = ((iz * H + iy) * W + ix) * xcs + half * 8;
     }
     bool lastValid = threadIdx.x + (NIT - 1) * BLK < NVOX * 2;
+    // halo coordinates of this thread's pieces, 12 bits each (ix:5 | iy:4 | iz:3), two per register: border tiles test
+    // coordinates with a few bit-field ops instead of re-deriving them by constant division per piece and tile
+    unsigned pk[(NIT + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (NIT + 1) / 2; i++) pk[i] = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int vox = (threadIdx.x + it * BLK) >> 1;
+        int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+        if (iz > 7) iz = 7;                                    // only the invalid tail pieces of the last iteration
+        pk[it >> 1] |= (unsigned)(ix | (iy << 5) | (iz << 9)) << ((it & 1) * 16);
+    }
     bf16x8 wf[WLDS ? 1 : NCH][WLDS ? 1 : 14][COB];
     if constexpr (WLDS) {
         for (int i = threadIdx.x; i < NWF * 64; i += BLK)
@@ -418,11 +430,10 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
         } else {
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                int idx = threadIdx.x + it * BLK;
-                int vox = idx >> 1;
-                int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
-                int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
-                bool inb = idx < NVOX * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                unsigned c = pk[it >> 1] >> ((it & 1) * 16);
+                unsigned gz = (unsigned)(z0 - 1) + ((c >> 9) & 7u), gy = (unsigned)(y0 - 1) + ((c >> 5) & 15u),
+                         gx = (unsigned)(x0 - 1) + (c & 31u);
+                bool inb = (it < NIT - 1 || lastValid) && gz < (unsigned)D && gy < (unsigned)H && gx < (unsigned)W;
                 sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (inb) sv[it] = *reinterpret_cast<const bf16x8*>(xb + rel[it]);
             }
