@@ -164,9 +164,9 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
     float dbs[2] = {0.f, 0.f};
     int64_t M = (int64_t)N * D * H * W;
     int64_t ntile = (M + UV - 1) / UV;
-    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-        constexpr int NA = (2 * UV * 2) / BLK, NB = (2 * 8 * UV * 2) / BLK;
-        bf16x8 va[NA], vb[NB];
+    constexpr int NA = (2 * UV * 2) / BLK, NB = (2 * 8 * UV * 2) / BLK;
+    bf16x8 va[NA], vb[NB];
+    auto load_tile = [&](int64_t tile) {
 #pragma unroll
         for (int it = 0; it < NA; it++) {
             int idx = threadIdx.x + it * BLK;
@@ -187,12 +187,17 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
                 vb[it] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0 + cb * 16 + half * 8);
             }
         }
+    };
+    // the next tile's global loads are issued before this tile's MFMAs (register prefetch)
+    if ((int64_t)blockIdx.x < ntile) load_tile(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NA; it++) *reinterpret_cast<bf16x8*>(xs + (threadIdx.x + it * BLK) * 8) = va[it];
 #pragma unroll
         for (int it = 0; it < NB; it++) *reinterpret_cast<bf16x8*>(gs + (threadIdx.x + it * BLK) * 8) = vb[it];
         __syncthreads();
+        if (tile + gridDim.x < ntile) load_tile(tile + gridDim.x);
         bf16x8 A[2];
 #pragma unroll
         for (int a = 0; a < 2; a++) A[a] = tr_frag(xsb, laneK + a * (UV * 32));
