@@ -844,7 +844,7 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
         }
     };
     // prefetch the next tile into registers while computing (only where the register file has room for it)
-    constexpr bool PF = (NT * CO_B * CI_B > 27) && (NT * CO_B * CI_B + NA + NB) * 4 <= 300;
+    constexpr bool PF = (NT * CO_B * CI_B + NA + NB) * 4 <= 300;
     if (PF && sb < ntiles) load_tile(sb);
     for (int tile = sb; tile < ntiles; tile += nsb) {
         if (!PF) load_tile(tile);
