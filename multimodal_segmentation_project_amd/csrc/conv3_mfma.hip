@@ -1112,18 +1112,18 @@ struct WgCfg { int cob, cib, nt, tg, nsb; };
 
 inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     WgCfg c;
-    c.cob = Cout % 32 == 0 ? 2 : 1;
-    // One ci block and all 27 taps per workgroup.  The kernel is bound by L2->LDS tile traffic, so what counts is MFMAs
-    // per staged byte: <2,1,27> stages 67 KB per 216 MFMAs/wave, the old <2,2,9> tap-group split 101 KB per 144.
-    // Cout = 16: the lean <1,1,27> kernel (2 workgroups/CU, 108 accumulator registers).
+    // One co block x one ci block x all 27 taps per workgroup (108 accumulator registers + register prefetch of the
+    // next tile = 248 VGPRs, 51 KB LDS -> 2 workgroups per CU).  Measured against fatter register blockings
+    // (<2,1,27>: 216 accumulators, 1 workgroup/CU; <2,2,9>): the second resident workgroup hides more than the
+    // extra staging of dy / x per (co, ci) pair costs, at every level.
+    c.cob = 1;
     c.cib = 1;
-    int groups = (Cout / (16 * c.cob)) * (Cin / (16 * c.cib));
+    int groups = (Cout / 16) * (Cin / 16);
     int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
-    int blocks = c.cob * c.cib;
     c.nt = 27;
     c.tg = 1;
-    // persistent: one round of workgroups (1 per CU for the 216-accumulator kernel, 2 per CU for the lean one)
-    int64_t want = (blocks == 1 ? 512 : 256) / (int64_t)groups;
+    // persistent: one round of workgroups, 2 per CU
+    int64_t want = 512 / (int64_t)groups;
     if (want < 1) want = 1;
     int64_t rounds = cdiv(ntiles, want);               // tiles per workgroup; then the fewest slabs that keep it
     c.nsb = (int)cdiv(ntiles, rounds);
@@ -1169,7 +1169,6 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     const bf16* xp = (const bf16*)x; const bf16* dp = (const bf16*)dy;
     int rc;
     if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s, xh);
-    else if (c.cob == 2 && c.cib == 1) rc = launch_wgrad<2, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s, xh);
     else { MI3D_CHECK_ARG(false, "conv3_mfma_wgrad: no kernel for this block config"); return -1; }
     MI3D_TRY(rc);
     if (dW && slab_sz >= (800 << 10))
