@@ -575,6 +575,10 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
 
 constexpr int PERSIST_WGS = 512;
 inline bool persist_ok(int Cin, int Cout, Geo g) {
+    // 16 -> 32 (two co blocks, 256 VGPRs): only worth it with >= 2 tiles per workgroup; the one-tile-per-workgroup
+    // generic kernel is faster below that (level 1 of the 96^3 net)
+    int64_t nt = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
+    if (Cin == 16 && Cout == 32 && nt < 1024) return false;
     return g.W >= 32 && g.H >= 16 && ((Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 16) || (Cin == 16 && Cout == 32)) &&
            !getenv("MI3D_NO_PERSIST");
 }
