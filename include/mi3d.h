@@ -116,6 +116,11 @@ size_t mi3d_seg_metrics_workspace_bytes(int C);
 /* out: device float[3] = {iou, dice, accuracy}; D = first spatial dim (reference loop bound, metrics.py:74,101) */
 int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,
                      void* workspace, void* stream);
+/* Evaluation.  Replaces the per-class mask/sum loops of test_model.py:255-276: exact counts of
+ * pred = argmax(logits) against labels in one pass.  counts: device int64[3*C + 1] =
+ * { n_inter[C] (pred==c && label==c), n_pred[C], n_label[C], n_correct };  same workspace as mi3d_seg_metrics. */
+int mi3d_seg_class_counts(const float* logits, const int64_t* labels, int N, int C, int64_t V, int64_t* counts,
+                          void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * DANN head.  Replaces train_dann.py:34-49 (DomainDiscriminator MLP 256-256-128-64-2, ReLU, Dropout 0.2) and

@@ -39,6 +39,11 @@ int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, i
     MI3D_CHECK_ARG(logits && labels && out && workspace, "mi3d_seg_metrics: null pointer");
     return seg_metrics(logits, labels, N, C, D, V, out, workspace, (hipStream_t)stream);
 }
+int mi3d_seg_class_counts(const float* logits, const int64_t* labels, int N, int C, int64_t V, int64_t* counts,
+                          void* workspace, void* stream) {
+    MI3D_CHECK_ARG(logits && labels && counts && workspace, "mi3d_seg_class_counts: null pointer");
+    return seg_metrics(logits, labels, N, C, 0, V, nullptr, workspace, (hipStream_t)stream, counts);
+}
 
 int mi3d_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int Nout, int relu,
                         const float* drop, void* stream) {

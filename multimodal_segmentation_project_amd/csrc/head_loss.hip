@@ -473,6 +473,21 @@ __global__ __launch_bounds__(1024) void seg_metrics_finalize_kernel(const unsign
     out[2] = (float)((double)counts[3 * MAXC] / ((double)N * (double)V));
 }
 
+// raw exact counts for the per-class evaluation metrics (test_model.py:242-285): out[0..C) n_inter, [C..2C) n_pred,
+// [2C..3C) n_tgt, [3C] n_correct  (int64)
+__global__ __launch_bounds__(1024) void seg_counts_finalize_kernel(const unsigned long long* part, int nblk, int C, long long* out) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int q = wave; q < 3 * MAXC + 1; q += 16) {
+        unsigned long long s = 0;
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * (3 * MAXC + 1) + q];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            if (q == 3 * MAXC) out[3 * C] = (long long)s;
+            else { int k = q / MAXC, c = q % MAXC; if (c < C) out[k * C + c] = (long long)s; }
+        }
+    }
+}
+
 constexpr int METRIC_BLOCKS = 1024;
 inline int sgrid(int64_t total, int cap) {
     int64_t w = (total + BLK - 1) / BLK;
@@ -577,7 +592,7 @@ int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teache
 size_t seg_metrics_ws_bytes(int C) { return (size_t)METRIC_BLOCKS * (3 * MAXC + 1) * sizeof(unsigned long long); }
 
 int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out, void* ws,
-                hipStream_t s) {
+                hipStream_t s, int64_t* counts_out) {
     MI3D_CHECK_ARG(C >= 1 && C <= MAXC, "seg_metrics: %d classes unsupported", C);
     MI3D_CHECK_ARG(N <= METRIC_BLOCKS, "seg_metrics: batch %d > %d unsupported", N, METRIC_BLOCKS);
     bool v4 = vv4(V, logits, labels);
@@ -589,7 +604,8 @@ int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D,
     else if (v4) seg_metrics_kernel<MAXC, 4><<<grid, BLK, 0, s>>>(logits, labels, C, V, cw);
     else seg_metrics_kernel<MAXC, 1><<<grid, BLK, 0, s>>>(logits, labels, C, V, cw);
     MI3D_LAUNCH_CHECK();
-    seg_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const unsigned long long*)ws, bx * N, N, C, D, V, out);
+    if (out) seg_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const unsigned long long*)ws, bx * N, N, C, D, V, out);
+    if (counts_out) seg_counts_finalize_kernel<<<1, 1024, 0, s>>>((const unsigned long long*)ws, bx * N, C, (long long*)counts_out);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -139,8 +139,8 @@ int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teache
                  LossCfg cfg, const float* coef, const float* grad_out, float* dlogits, hipStream_t s);
 size_t seg_metrics_ws_bytes(int C);
 // out: device float[3] = {iou, dice, acc}; Q1 loop bound = first spatial dim D (utils/metrics.py:74,101)
-int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,
-                void* ws, hipStream_t s);
+int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out, void* ws,
+                hipStream_t s, int64_t* counts_out = nullptr);
 
 // ---- misc ---------------------------------------------------------------------------------- misc.hip
 int ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int dcs, int C, int N, int64_t V, hipStream_t s);

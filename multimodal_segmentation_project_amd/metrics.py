@@ -161,3 +161,31 @@ def calculate_dice(pred, target):
 
 def calculate_accuracy(pred, target):
     return calculate_all(pred, target)[2]
+
+
+# ---- evaluation metrics ------------------------------------------------------------------------
+def class_counts(pred, target):
+    """Exact int64 counts of argmax(pred) against target in one pass: tensor[3*C+1] =
+    {n_inter[C], n_pred[C], n_label[C], n_correct} (device)."""
+    n, c, v, labels = _prep(pred, target)
+    p32 = pred.detach().contiguous().float()
+    out = torch.empty(3 * c + 1, dtype=torch.int64, device=pred.device)
+    ws = torch.empty(_lib.lib().mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=pred.device)
+    call("mi3d_seg_class_counts", ptr(p32), ptr(labels), n, c, v, ptr(out), ptr(ws), stream_ptr())
+    return out
+
+
+def per_class_dice_iou(pred, target, classes=(1, 2, 3)):
+    """Per-class Dice / IoU of the reference's test script [test_model.py:255-276]: a class absent from the label
+    scores 0.0 for both (unlike calculate_dice/iou, which skip it).  Returns {class: (dice, iou)} of Python floats
+    (one host sync, like the reference's .item() calls)."""
+    c = pred.shape[1]
+    cnt = class_counts(pred, target).cpu().tolist()
+    res = {}
+    for k in classes:
+        if k >= c or cnt[2 * c + k] == 0:
+            res[k] = (0.0, 0.0)
+            continue
+        inter, npred, nlab = float(cnt[k]), float(cnt[c + k]), float(cnt[2 * c + k])
+        res[k] = ((2.0 * inter + 1e-5) / (npred + nlab + 1e-5), (inter + 1e-5) / (npred + nlab - inter + 1e-5))
+    return res

@@ -577,3 +577,31 @@ def test_upconv_mfma_vs_c_oracle(orc, shape):
     assert np.abs(gotx - rgx).max() <= np.abs(rgx).max() * 2 ** -8 + 1e-6
     np.testing.assert_allclose(dW.cpu().numpy(), rgw, rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), rgb, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_eval_per_class_metrics_and_counts():
+    """per-class Dice/IoU of test_model.py:255-276 (absent class -> 0.0) and the exact count pass,
+    against a literal torch restatement of those lines on the CPU."""
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(2, 4, 12, 20, 28, generator=g)
+    label = torch.randint(0, 3, (2, 1, 12, 20, 28), generator=g)          # class 3 absent from the labels
+    got = M.per_class_dice_iou(logits.to(DEV), label.to(DEV))
+    pred_classes = torch.argmax(logits, dim=1)
+    label_classes = label.squeeze(1)
+    for c in (1, 2, 3):
+        pm, lm = pred_classes == c, label_classes == c
+        if lm.sum() > 0:
+            inter = (pm & lm).sum().float()
+            dice = ((2. * inter + 1e-5) / (pm.sum() + lm.sum() + 1e-5)).item()
+            iou = ((inter + 1e-5) / (pm.sum() + lm.sum() - inter + 1e-5)).item()
+        else:
+            dice = iou = 0.0
+        assert abs(got[c][0] - dice) < 1e-6 and abs(got[c][1] - iou) < 1e-6, (c, got[c], dice, iou)
+    assert got[3] == (0.0, 0.0)
+    cnt = M.class_counts(logits.to(DEV), label.to(DEV)).cpu()
+    for c in range(4):
+        assert cnt[c].item() == int(((pred_classes == c) & (label_classes == c)).sum())
+        assert cnt[4 + c].item() == int((pred_classes == c).sum())
+        assert cnt[8 + c].item() == int((label_classes == c).sum())
+    assert cnt[12].item() == int((pred_classes == label_classes).sum())
