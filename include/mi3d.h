@@ -145,6 +145,11 @@ int mi3d_softmax_ce_rows(const float* logits, const int64_t* labels, int M, int 
  * ---------------------------------------------------------------------------------------------------------- */
 int mi3d_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float grad_scale, int64_t* step_dev, void* stream);
+/* Same update over ONE contiguous range of the arena without (increment = 0) or with the step increment: a step over
+ * several trainable ranges (frozen encoder, train_unet.py:31-43,413-431) = one call per range, increment on the last;
+ * n = 0 with increment = 1 only advances the counter. */
+int mi3d_adamw_apply(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float grad_scale, int64_t* step_dev, int increment, void* stream);
 /* Dropout3d (unet.py:14,18) channel masks: out[i] = 0 w.p. p else 1/(1-p); state_dev = device uint64[2]
  * {seed, counter}, counter advanced by n.  Counter-based RNG: same distribution as torch, different stream. */
 int mi3d_dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, void* stream);

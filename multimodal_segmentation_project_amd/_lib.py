@@ -53,6 +53,7 @@ _SIGS = {
     "mi3d_linear_backward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp]),
     "mi3d_softmax_ce_rows": (i32, [vp, vp, i32, i32, vp, vp, f32, vp]),
     "mi3d_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp]),
+    "mi3d_adamw_apply": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, i32, vp]),
     "mi3d_dropout_scales": (i32, [vp, i64, f32, vp, vp]),
     "mi3d_conv3_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "mi3d_conv3_forward": (i32, [i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),

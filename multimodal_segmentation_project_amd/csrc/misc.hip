@@ -273,11 +273,15 @@ int softmax_ce_rows(const float* logits, const int64_t* labels, int M, int C, fl
 }
 
 int adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-               float wd, float grad_scale, int64_t* step_dev, hipStream_t s) {
-    adamw_kernel<<<sgrid(n, 4096), BLK, 0, s>>>(p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step_dev);
-    MI3D_LAUNCH_CHECK();
-    step_inc_kernel<<<1, 1, 0, s>>>(step_dev);
-    MI3D_LAUNCH_CHECK();
+               float wd, float grad_scale, int64_t* step_dev, hipStream_t s, int increment) {
+    if (n > 0) {
+        adamw_kernel<<<sgrid(n, 4096), BLK, 0, s>>>(p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step_dev);
+        MI3D_LAUNCH_CHECK();
+    }
+    if (increment) {
+        step_inc_kernel<<<1, 1, 0, s>>>(step_dev);
+        MI3D_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -159,7 +159,7 @@ int softmax_ce_rows(const float* logits, const int64_t* labels, int M, int C, fl
                     float scale, hipStream_t s);
 // fused flat AdamW (torch.optim.AdamW semantics, train_unet.py:378); step_dev: device int64 step counter (incremented)
 int adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-               float eps, float wd, float grad_scale, int64_t* step_dev, hipStream_t s);
+               float eps, float wd, float grad_scale, int64_t* step_dev, hipStream_t s, int increment = 1);
 // Dropout3d channel masks: out[i] = (u_i >= p) ? 1/(1-p) : 0, counter-based RNG; state_dev = {seed, counter}
 int dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, hipStream_t s);
 int fill_f32(float* p, int64_t n, float v, hipStream_t s);

@@ -74,6 +74,15 @@ class TrainStep:
         if self.world > 1:
             self.broadcast_parameters()
 
+    def reset_optimizer(self):
+        """What rebuilding ``optim.AdamW`` does in the reference when the encoder is (un)frozen
+        (train_unet.py:413-431, finetune_ct.py:374-381): moments and step count start from zero."""
+        self.arena.m.zero_()
+        self.arena.v.zero_()
+        self.arena.step.zero_()
+        self._graph = None
+        self._static = None
+
     # ---- DDP construction semantics (SURVEY C1): rank 0's parameters and buffers win
     def broadcast_parameters(self):
         self.comm.broadcast_parameters(self.model.buffers())
@@ -85,12 +94,16 @@ class TrainStep:
     def _prepare(self, x):
         dt = self.dtype or engine.resolve_compute_dtype(self.model)
         desc = engine.build_desc(self.model, x, dt)
-        key = (tuple(x.shape), dt)
+        # frozen parameters (requires_grad=False: encoder/bottleneck freezing of train_unet.py:31-43, finetune_ct.py:270-304)
+        # are part of the static state: they get no gradient, no optimizer update, and trailing all-frozen backward
+        # segments are not run at all
+        trainable = tuple(bool(p.requires_grad) for p in self.arena.params)
+        key = (tuple(x.shape), dt, trainable)
         if self._static is not None and self._static["key"] == key:
             return self._static
         L = desc.n_levels
         lib = _lib.lib()
-        st = {"key": key, "desc": desc, "L": L}
+        st = {"key": key, "desc": desc, "L": L, "trainable": trainable}
         st["ws_bytes"] = lib.mi3d_unet_workspace_bytes(C.byref(desc))
         if st["ws_bytes"] == 0:
             _lib.check(-1, "mi3d_unet_workspace_bytes")
@@ -109,7 +122,27 @@ class TrainStep:
         st["ndrop"] = lib.mi3d_unet_dropout_count(C.byref(desc))
         st["drop"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
         st["ptab"] = ptr_table([p.data_ptr() for p in self.arena.params])
-        st["gtab"] = ptr_table(self.arena.grad_ptrs())
+        st["gtab"] = ptr_table([gp if t else None for gp, t in zip(self.arena.grad_ptrs(), trainable)])
+        # contiguous trainable arena ranges for the optimizer, and the number of backward segments that still matter
+        a = self.arena
+        ranges = []
+        for i, t in enumerate(trainable):
+            if not t:
+                continue
+            lo, hi = a.range_of(i, i + 1)
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1] = (ranges[-1][0], hi)
+            else:
+                ranges.append((lo, hi))
+        st["opt_ranges"] = ranges
+        nseg, last = 2 * L + 2, -1
+        r = (C.c_int * 4)()
+        for seg in range(nseg):
+            _lib.check(lib.mi3d_unet_segment_params(C.byref(desc), seg, r), "mi3d_unet_segment_params")
+            idx = list(range(r[0], r[1])) + (list(range(r[2], r[3])) if r[2] >= 0 else [])
+            if any(trainable[i] for i in idx):
+                last = seg
+        st["nseg_run"] = last + 1
         st["btab"] = ptr_table([b.data_ptr() for b in self.model.buffers()])
         if self.teacher is not None:
             st["t_ws"] = torch.empty(st["ws_bytes"], dtype=torch.uint8, device=dev)
@@ -147,7 +180,7 @@ class TrainStep:
              ptr(st["metrics"]), ptr(st["coef"]), ptr(st["loss_ws"]), s)
         call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
              ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
-        nseg = 2 * L + 2
+        nseg = st["nseg_run"]
         do_comm = self.world > 1 and boundary
         for seg in range(nseg):
             call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop), ptr(st["dlogits"]),
@@ -162,8 +195,11 @@ class TrainStep:
              ptr(st["met_ws"]), s)
         if boundary:
             a = self.arena
-            call("mi3d_adamw_step", ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), a.numel, self.lr, self.betas[0],
-                 self.betas[1], self.eps, self.wd, 1.0, ptr(a.step), s)
+            rng = st["opt_ranges"]
+            for k, (lo, hi) in enumerate(rng):
+                call("mi3d_adamw_apply", a.p.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, a.m.data_ptr() + 4 * lo,
+                     a.v.data_ptr() + 4 * lo, hi - lo, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, 1.0,
+                     ptr(a.step), int(k == len(rng) - 1), s)
         self.micro += 1
 
     def _allreduce_bucket(self, seg):
