@@ -45,6 +45,7 @@ class TrainStep:
         self.model = model
         self.teacher = kd_teacher
         self.cfg = _loss_cfg(loss, kd_alpha if kd_teacher is not None else None, kd_temperature)
+        self._graph = None
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.accum = int(grad_accum)
         self.micro = 0
@@ -73,6 +74,17 @@ class TrainStep:
         self.inv_accum = torch.full((), 1.0 / self.accum, dtype=torch.float32, device=self.device)
         if self.world > 1:
             self.broadcast_parameters()
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        """Learning rate (ReduceLROnPlateau of train_unet.py:381,442 is host policy: assign the new value here).  The
+        value is a kernel argument, so a captured step graph is dropped and re-captured on the next step."""
+        self._lr = float(value)
+        self._graph = None
 
     def reset_optimizer(self):
         """What rebuilding ``optim.AdamW`` does in the reference when the encoder is (un)frozen
