@@ -1030,6 +1030,112 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_c1_kernel(const float* __rest
         slab[nW + co0 + threadIdx.x] = (red[threadIdx.x] + red[16 + threadIdx.x]) + (red[32 + threadIdx.x] + red[48 + threadIdx.x]);
 }
 
+// ---- first layer forward (Cin = 1, fp32 input): y[v][co] = b[co] + sum_tap w[co][tap] * x[v + tap].
+// With one input channel the fp32-FMA kernel is VALU-bound (432 FMAs per voxel = 28 us at 96^3 N=2); as an MFMA
+// the work is nothing: K = taps.  K layout: two K-steps; k = 8*kg + 4*h + dx' in step A holds tap ((dz,dy) pair
+// 2*kg + h, dx = dx'), dx' = 3 is a zero-weight pad; step B holds the ninth (dz,dy) pair (2,2) in kg = 0, h = 0.
+// So a lane's 8 k-values are two runs of 4 CONSECUTIVE x positions -> two ds_read_b64 from a bf16 halo tile that is
+// stored four times, pre-shifted by 0..3 elements (copy s holds x[i+s] at i), so the run of voxel x starts 8-byte
+// aligned in copy (x & 3).  Persistent workgroups, tile 4 x 8 x 16 (wave = z-slice), BN partial sums like the
+// persistent conv kernel.
+constexpr int C1F_LD = 24;                         // row pitch (elements) of one shifted copy: 18 halo + pad, 8-B aligned rows
+__global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                                const float* __restrict__ bias, bf16* __restrict__ y, int ycs,
+                                                                int Cout, int N, int D, int H, int W, int tilesZ, int tilesY,
+                                                                int tilesX, float* __restrict__ part) {
+    constexpr int ROWS = WIZ * WIY;                 // 60 halo rows
+    __shared__ __attribute__((aligned(16))) bf16 xsh[4 * ROWS * C1F_LD];
+    __shared__ float red[4][16][2];
+    int co0 = blockIdx.y * 16;
+    int lane = threadIdx.x & 63;
+    int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int vn = lane & 15, kg = lane >> 4;
+    // A fragments (weights), built once: lane (co = vn, kg)
+    bf16x8 wa, wb;
+    {
+        const float* wr = wgt + (int64_t)(co0 + vn) * 27;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int pair = 2 * kg + (j >> 2), dx = j & 3;
+            wa[j] = (bf16)((dx < 3) ? wr[pair * 3 + dx] : 0.f);
+            wb[j] = (bf16)((kg == 0 && j < 3) ? wr[24 + j] : 0.f);
+        }
+    }
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bv[j] = bias ? bias[co0 + kg * 4 + j] : 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // B fragment addressing: copy (vn & 3), element 4*(vn >> 2) of the row; rows of the two (dz,dy) pairs of this lane
+    int cpy = vn & 3, e0 = (vn >> 2) * 4;
+    int rowA0 = ((2 * kg) / 3) * WIY + (2 * kg) % 3, rowA1 = ((2 * kg + 1) / 3) * WIY + (2 * kg + 1) % 3;
+    int offA0 = (cpy * ROWS + rowA0) * C1F_LD + e0, offA1 = (cpy * ROWS + rowA1) * C1F_LD + e0;
+    int offB = (cpy * ROWS + 2 * WIY + 2) * C1F_LD + e0;
+    int ntiles = N * tilesZ * tilesY * tilesX;
+    // pad elements (index > 17 - shift) are never written by the staging loop: zero them once, they meet zero weights
+    for (int idx = threadIdx.x; idx < 4 * ROWS * C1F_LD; idx += BLK) xsh[idx] = (bf16)0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        int tx_ = t % tilesX; t /= tilesX;
+        int ty_ = t % tilesY; t /= tilesY;
+        int tz_ = t % tilesZ; int n = t / tilesZ;
+        int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < ROWS * WIX; idx += BLK) {
+            int h = idx % WIX, row = idx / WIX;
+            int iy = row % WIY, iz = row / WIY;
+            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + h;
+            float v = 0.f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[(((int64_t)n * D + gz) * H + gy) * W + gx];
+            bf16 vb = (bf16)v;
+#pragma unroll
+            for (int sft = 0; sft < 4; sft++) {              // copy sft holds x[i + sft] at i
+                int i = h - sft;
+                if (i >= 0) xsh[(sft * ROWS + row) * C1F_LD + i] = vb;
+            }
+        }
+        __syncthreads();
+        int gz = z0 + wave, gx = x0 + vn;
+        bool okzx = gz < D && gx < W;
+        bf16* yrow = y + ((((int64_t)n * D + gz) * H + y0) * W + gx) * ycs + co0 + kg * 4;
+        int wbase = wave * WIY * C1F_LD;
+#pragma unroll
+        for (int r = 0; r < WTY; r++) {
+            int rb = wbase + r * C1F_LD;
+            bf16x4 a0 = *reinterpret_cast<const bf16x4*>(xsh + offA0 + rb), a1 = *reinterpret_cast<const bf16x4*>(xsh + offA1 + rb);
+            bf16x4 b0 = *reinterpret_cast<const bf16x4*>(xsh + offB + rb);
+            bf16x8 fa = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            bf16x8 fb = {b0[0], b0[1], b0[2], b0[3], b0[0], b0[1], b0[2], b0[3]};
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = mfma16(wa, fa, acc);
+            acc = mfma16(wb, fb, acc);
+            bool ok = okzx && (y0 + r) < H;
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                o[j] = (bf16)(acc[j] + bv[j]);
+                float q = ok ? (float)o[j] : 0.f;
+                s1[j] += q; s2[j] = fmaf(q, q, s2[j]);
+            }
+            if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs) = o;
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float a = s1[j], b = s2[j];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (vn == 0) { red[wave][kg * 4 + j][0] = a; red[wave][kg * 4 + j][1] = b; }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32; idx += BLK) {
+            int k = idx & 1, chn = idx >> 1;
+            float v = (red[0][chn][k] + red[1][chn][k]) + (red[2][chn][k] + red[3][chn][k]);
+            part[((int64_t)blockIdx.x * 2 + k) * Cout + co0 + chn] = v;
+        }
+    }
+}
+
 // fixed-order parallel slab sum: block = EW elements x 256/EW slab groups (EW = 8 when the slab is small and the
 // parallelism has to come from the slab dimension).  MFMA_LAYOUT: slab elements are in the (tap, co-block, ci-block,
 // lane, reg) order written above and are un-permuted to torch's (Cout, Cin, 27) here.
@@ -1197,6 +1303,22 @@ int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo 
                                                cdiv(g.W, WTX), ws);
     MI3D_LAUNCH_CHECK();
     slab_reduce2_kernel<false, 8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, 1, Cout);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+// first layer forward: x fp32 single channel (N,D,H,W), y bf16 channels-last, Cout % 16 == 0; part != NULL -> BN partial
+// sums [conv3_c1_fwd_stat_blocks][2][Cout] of the stored (rounded) values
+int conv3_c1_fwd_stat_blocks(Geo g) {
+    int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
+    return (int)(ntiles < 1024 ? ntiles : 1024);
+}
+int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,
+                      hipStream_t s) {
+    MI3D_CHECK_ARG(Cout % 16 == 0 && ycs % 4 == 0 && ((uintptr_t)y % 8) == 0, "conv3_c1_fwd_mfma: unsupported channels");
+    dim3 grid((unsigned)conv3_c1_fwd_stat_blocks(g), (unsigned)(Cout / 16));
+    conv3_c1_fwd_mfma_kernel<<<grid, BLK, 0, s>>>(x, w, bias, (bf16*)y, ycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ),
+                                                  cdiv(g.H, WTY), cdiv(g.W, WTX), part);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

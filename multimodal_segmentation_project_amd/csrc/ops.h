@@ -56,6 +56,10 @@ size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
                      int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh = Halves());
 
+// first layer (Cin = 1, fp32 input) forward on the matrix cores (K = taps); optional BN partial sums like conv3_mfma_fwd
+int conv3_c1_fwd_stat_blocks(Geo g);
+int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,
+                      hipStream_t s);
 int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db, int accumulate,
                         float* ws, size_t ws_floats, hipStream_t s);
 

@@ -126,6 +126,10 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
             H.drop_off = drop_off;
             drop_off += (int64_t)d->N * cout;
             bool c1 = p.dt == MI3D_BF16 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT");
+            if (c1) {
+                size_t sp = (size_t)conv3_c1_fwd_stat_blocks(g) * 2 * cout;
+                if (sp > statpart_floats) statpart_floats = sp;
+            }
             size_t wf = (H.mfma || c1) ? conv3_mfma_wgrad_ws_floats(H.Cin, H.Cout, g) : conv3_direct_wgrad_ws_floats(H.Cin, H.Cout, g);
             if (wf > wg_floats) wg_floats = wf;
         }
@@ -221,7 +225,7 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         bool fused_stats = false;
         void* zo = h == 0 ? c.at(B.z1) : zout;
         int zocs = h == 0 ? H.Cout : zcs;
-        int ksd = 0;
+        int ksd = 0, c1_blocks = 0;
         if (H.mfma) {
             if (!c.packed) MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
             // training: a split-K launch leaves its finishing pass to the statistics kernel (ksd = split factor)
@@ -229,13 +233,19 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
                                     training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
                                     (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr));
             fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
+        } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT") &&
+                   !getenv("MI3D_NO_C1_MFMA")) {
+            // first layer on the matrix cores (taps are the K dimension), BN partial sums fused like the other convs
+            MI3D_TRY(conv3_c1_fwd_mfma((const float*)in, c.P(H.pidx), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
+                                       training ? c.at<float>(p.statpart) : nullptr, c.s));
+            if (training) { fused_stats = true; c1_blocks = conv3_c1_fwd_stat_blocks(g); }
         } else {
             MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), c.at<float>(H.wpd), c.s));
             MI3D_TRY(conv3_direct_fwd(idt, p.dt, in, ics, H.Cin, c.at<float>(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout,
                                       H.Cout, g, c.s));
         }
         if (fused_stats) {
-            MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
+            MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
                                        c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.s));
         } else if (training && ksd > 0) {
             MI3D_TRY(bn_train_stats_splitk(c.at<float>(p.skws), ksd, c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2),
