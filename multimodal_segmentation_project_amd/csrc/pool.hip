@@ -14,8 +14,11 @@ __global__ __launch_bounds__(BLK) void maxpool2_fwd_kernel(const T* __restrict__
     int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
     int64_t total = (int64_t)N * Do * Ho * Wo * G;
     for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
-        int g = (int)(idx % G); int64_t r = idx / G;
-        int wo = (int)(r % Wo); r /= Wo; int ho = (int)(r % Ho); r /= Ho; int d_o = (int)(r % Do); int n = (int)(r / Do);
+        // 32-bit index math (total < 2^31 checked by the launcher): a 64-bit div/mod costs ~80 instructions
+        unsigned iu = (unsigned)idx, r = iu / (unsigned)G;
+        int g = (int)(iu - r * (unsigned)G);
+        int wo = (int)(r % (unsigned)Wo); r /= (unsigned)Wo; int ho = (int)(r % (unsigned)Ho); r /= (unsigned)Ho;
+        int d_o = (int)(r % (unsigned)Do); int n = (int)(r / (unsigned)Do);
         float m[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; i++) m[i] = -INFINITY;
@@ -41,8 +44,10 @@ __global__ __launch_bounds__(BLK) void maxpool2_bwd_kernel(const T* __restrict__
     int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
     int64_t total = (int64_t)N * Do * Ho * Wo * G;
     for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
-        int g = (int)(idx % G); int64_t r = idx / G;
-        int wo = (int)(r % Wo); r /= Wo; int ho = (int)(r % Ho); r /= Ho; int d_o = (int)(r % Do); int n = (int)(r / Do);
+        unsigned iu = (unsigned)idx, r = iu / (unsigned)G;
+        int g = (int)(iu - r * (unsigned)G);
+        int wo = (int)(r % (unsigned)Wo); r /= (unsigned)Wo; int ho = (int)(r % (unsigned)Ho); r /= (unsigned)Ho;
+        int d_o = (int)(r % (unsigned)Do); int n = (int)(r / (unsigned)Do);
         float v[8][VEC], m[VEC], gp[VEC];
         int arg[VEC];
 #pragma unroll
@@ -81,6 +86,7 @@ inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
 int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int pcs, hipStream_t s) {
     MI3D_CHECK_ARG(g.D % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0, "maxpool2: odd spatial size %dx%dx%d unsupported", g.D, g.H, g.W);
+    MI3D_CHECK_ARG(g.M() / 8 * C < (1ll << 31), "maxpool2: more than 2^31 pooled elements");
     int64_t nout = g.M() / 8;
     DISPATCH_T(dtype, T, {
         if (C % 8 == 0 && zcs % 8 == 0 && pcs % 8 == 0 && al16(z) && al16(p))
@@ -95,6 +101,7 @@ int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int p
 int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs, void* dz,
                  int dzcs, int C, Geo g, hipStream_t s) {
     MI3D_CHECK_ARG(g.D % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0, "maxpool2_bwd: odd spatial size unsupported");
+    MI3D_CHECK_ARG(g.M() / 8 * C < (1ll << 31), "maxpool2_bwd: more than 2^31 pooled elements");
     int64_t nout = g.M() / 8;
     DISPATCH_T(dtype, T, {
         bool v8 = C % 8 == 0 && zcs % 8 == 0 && dpcs % 8 == 0 && dzcs % 8 == 0 && (!dskip || dskipcs % 8 == 0) &&

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __rest
         bf16x8 Bf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) Bf[ks] = *reinterpret_cast<const bf16x8*>(x + vc * xcs + 32 * ks + 8 * G);
-        int w_ = (int)(vc % W); int64_t r = vc / W; int h_ = (int)(r % H); r /= H; int d_ = (int)(r % D); int n = (int)(r / D);
+        // 32-bit index math (M < 2^31 checked by the launcher): 64-bit div/mod cost ~80 instructions each
+        unsigned vu = (unsigned)vc; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
 #pragma unroll
         for (int tap = 0; tap < 8; tap++) {
             int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* _
         int64_t v = grp * 16 + vn;
         bool ok = v < M;
         int64_t vc = ok ? v : M - 1;
-        int w_ = (int)(vc % W); int64_t r = vc / W; int h_ = (int)(r % H); r /= H; int d_ = (int)(r % D); int n = (int)(r / D);
+        // 32-bit index math (M < 2^31 checked by the launcher): 64-bit div/mod cost ~80 instructions each
+        unsigned vu = (unsigned)vc; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
         bf16x8 Bf[S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
             int64_t v = tile * UV + vox;
             vb[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (v < M && cb < cbn) {
-                int w_ = (int)(v % W); int64_t r = v / W; int h_ = (int)(r % H); r /= H; int d_ = (int)(r % D); int n = (int)(r / D);
+                unsigned vu = (unsigned)v; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
                 int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
                 vb[it] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0 + cb * 16 + half * 8);
             }
@@ -299,6 +301,7 @@ int upconv2_mfma_pack(const float* w, int Cin, int Cout, void* wp, hipStream_t s
 int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
                      hipStream_t s) {
     MI3D_CHECK_ARG(upconv2_mfma_supported(Cin, Cout, xcs, ycs), "upconv2_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
+    MI3D_CHECK_ARG(g.M() < (1ll << 31), "upconv2_mfma_fwd: more than 2^31 input voxels");
     const bf16* xp = (const bf16*)x; const bf16* wf = (const bf16*)wp; bf16* yp = (bf16*)y;
     int gx = wave_grid(g.M());
     int gy = 1;
@@ -318,6 +321,7 @@ size_t upconv2_mfma_bwd_ws_floats(int Cin, int Cout, Geo g) {
 int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, int Cout, const void* wp, void* dx, int dxcs,
                      float* dW, float* db, int accumulate, float* ws, size_t ws_floats, Geo g, hipStream_t s) {
     MI3D_CHECK_ARG(upconv2_mfma_supported(Cin, Cout, xcs, gycs), "upconv2_mfma_bwd: unsupported channels");
+    MI3D_CHECK_ARG(g.M() < (1ll << 31), "upconv2_mfma_bwd: more than 2^31 input voxels");
     const bf16* xp = (const bf16*)x; const bf16* gp = (const bf16*)gy;
     const bf16* wb = (const bf16*)wp + (size_t)Cin * Cout * 8;
     if (dx) {
