@@ -287,3 +287,37 @@ def test_lr_change_reaches_a_captured_graph():
     ts.lr = 1e-3
     ts.step_static()
     assert not torch.equal(m.final_conv.weight, w0)
+
+
+@pytest.mark.gpu
+def test_reference_volume_shape_192():
+    """The reference trains/evaluates on 192^3 whole volumes, batch 1 (run_training.sh / test_model.py).  One bf16 train
+    step + eval at that shape: finite, bitwise reproducible, and the train-mode Dice of the bf16 path within 1e-3 of the
+    exact fp32 path on the same weights (BASELINE parity bar) -- size-independent properties at the real size."""
+    import multimodal_segmentation_project_amd as mi
+    from multimodal_segmentation_project_amd.trainer import TrainStep
+    dev = torch.device("cuda")
+    S = 192
+    g = torch.Generator().manual_seed(1234)
+    q = S // 4
+    idx = torch.arange(S) // q
+    lab = ((idx[:, None, None] + idx[None, :, None] + idx[None, None, :]) % 4).to(torch.int64)       # blocky labels
+    y = lab[None, None].contiguous()
+    x = (lab.float() / 3 + 0.1 * torch.randn(S, S, S, generator=g))[None, None].contiguous()
+    x, y = x.to(dev), y.to(dev)
+
+    def one(dtype):
+        torch.manual_seed(0)
+        m = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).train()
+        ts = TrainStep(m, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=dtype)
+        out = ts.step(x, y).cpu()
+        ev = ts.evaluate(x, y).cpu()
+        return out, ev
+
+    a, ea = one(torch.bfloat16)
+    b, eb = one(torch.bfloat16)
+    assert torch.isfinite(a).all() and torch.isfinite(ea).all()
+    assert torch.equal(a, b) and torch.equal(ea, eb)
+    c, _ = one(torch.float32)
+    assert abs(float(a[0]) - float(c[0])) < 5e-3 * abs(float(c[0]))          # loss
+    assert abs(float(a[2]) - float(c[2])) < 1e-3                               # Dice
