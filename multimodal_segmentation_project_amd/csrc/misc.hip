@@ -212,7 +212,8 @@ __global__ void scale_add_kernel(float* dst, const float* src, int64_t n, float 
 
 int slab_reduce(const float* slabs, int nslab, int64_t slab_sz, int64_t nW, float* dW, float* db, int accumulate,
                 hipStream_t s) {
-    if (slab_sz < 1024) slab_reduce_kernel<4><<<cdiv(slab_sz, 4), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
+    if (slab_sz < 128) slab_reduce_kernel<1><<<(unsigned)slab_sz, BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
+    else if (slab_sz < 1024) slab_reduce_kernel<4><<<cdiv(slab_sz, 4), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
     else if (slab_sz < (16 << 10)) slab_reduce_kernel<8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
     else slab_reduce_kernel<32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(slabs, nslab, slab_sz, nW, dW, db, accumulate);
     MI3D_LAUNCH_CHECK();
