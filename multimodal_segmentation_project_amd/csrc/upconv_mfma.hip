@@ -76,6 +76,8 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __rest
         unsigned vu = (unsigned)vc; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
 #pragma unroll
         for (int tap = 0; tap < 8; tap++) {
+            // few voxels (deep levels): the launcher spreads the 8 taps over blockIdx.z -> 8x shorter dependent chain
+            if (gridDim.z > 1 && tap != (int)blockIdx.z) continue;
             int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
             bf16* yp = y + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * ycs + 4 * G;
             for (int cob = blockIdx.y; cob < COBN; cob += gridDim.y) {
@@ -122,6 +124,49 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* _
             bf16x4 o = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
             if (ok) *reinterpret_cast<bf16x4*>(dx + v * dxcs + cib * 16 + 4 * G) = o;
         }
+    }
+}
+
+// Few voxels, many K-steps (deep levels): one workgroup per 16-voxel group and channel block; the S K-steps are split
+// over the 4 waves (each loads S/4 gathered fragments + S/4 weight fragments) and summed through LDS -> the dependent
+// load -> MFMA chain is 4x shorter and there are 4x more workgroups.
+template <int S>
+__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_ks_kernel(const bf16* __restrict__ g, int gcs, int Cout,
+                                                                      const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
+                                                                      int Cin, int N, int D, int H, int W) {
+    static_assert(S % 4 == 0, "K-steps split over 4 waves");
+    constexpr int SW = S / 4;
+    __shared__ float red[4][64][4];
+    int64_t M = (int64_t)N * D * H * W;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, vn = lane & 15, G = lane >> 4;
+    int64_t v = (int64_t)blockIdx.x * 16 + vn;
+    bool ok = v < M;
+    int64_t vc = ok ? v : M - 1;
+    unsigned vu = (unsigned)vc; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
+    bf16x8 Bf[SW];
+#pragma unroll
+    for (int i = 0; i < SW; i++) {
+        int s = wave * SW + i;
+        int kk0 = 32 * s + 8 * G, tap = kk0 / Cout, co0 = kk0 % Cout;
+        int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
+        Bf[i] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0);
+    }
+    int cib = blockIdx.y;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bf16* wp = wb + ((int64_t)cib * S + wave * SW) * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < SW; i++) acc = mfma16(*reinterpret_cast<const bf16x8*>(wp + i * 512), Bf[i], acc);
+    *reinterpret_cast<f32x4*>(&red[wave][lane][0]) = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 t = acc;
+#pragma unroll
+        for (int wv = 1; wv < 4; wv++) {
+            f32x4 u = *reinterpret_cast<const f32x4*>(&red[wv][lane][0]);
+            t[0] += u[0]; t[1] += u[1]; t[2] += u[2]; t[3] += u[3];
+        }
+        bf16x4 o = {(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
+        if (ok) *reinterpret_cast<bf16x4*>(dx + v * dxcs + cib * 16 + 4 * G) = o;
     }
 }
 
@@ -306,7 +351,8 @@ int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const floa
     int gx = wave_grid(g.M());
     int gy = 1;
     while (gx * gy < 512 && gy < Cout / 16) gy *= 2;      // few voxels (deep levels): parallelise over channel blocks
-    dim3 grid((unsigned)gx, (unsigned)gy);
+    int gz = (gx * gy < 512 && !(Cin == 32 && Cout == 16)) ? 8 : 1;     // ... and over the 8 taps
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
 #define UF(K) upconv_mfma_fwd_kernel<K><<<grid, BLK, 0, s>>>(xp, xcs, wf, bias, yp, ycs, Cout, g.N, g.D, g.H, g.W)
     switch (Cin / 32) { case 1: UF(1); break; case 2: UF(2); break; case 4: UF(4); break; default: UF(8); break; }
 #undef UF
@@ -331,7 +377,16 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         dim3 grid((unsigned)gx, (unsigned)gy);
         bf16* dp = (bf16*)dx;
 #define UB(SS) upconv_mfma_bwd_data_kernel<SS><<<grid, BLK, 0, s>>>(gp, gycs, Cout, wb, dp, dxcs, Cin, g.N, g.D, g.H, g.W)
-        switch (Cout / 4) { case 4: UB(4); break; case 8: UB(8); break; case 16: UB(16); break; default: UB(32); break; }
+#define UBK(SS) upconv_mfma_bwd_data_ks_kernel<SS><<<gridk, BLK, 0, s>>>(gp, gycs, Cout, wb, dp, dxcs, Cin, g.N, g.D, g.H, g.W)
+        dim3 gridk((unsigned)cdiv(g.M(), 16), (unsigned)(Cin / 16));
+        bool ksp = gx * gy < 512 && Cout / 4 >= 8 && (int64_t)gridk.x * gridk.y <= 8192;     // deep levels
+        switch (Cout / 4) {
+            case 4: UB(4); break;
+            case 8: if (ksp) UBK(8); else UB(8); break;
+            case 16: if (ksp) UBK(16); else UB(16); break;
+            default: if (ksp) UBK(32); else UB(32); break;
+        }
+#undef UBK
 #undef UB
         MI3D_LAUNCH_CHECK();
     }
