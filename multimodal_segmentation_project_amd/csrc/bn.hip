@@ -270,7 +270,9 @@ inline bool vec8_ok(int C, int cs_a, int cs_b, const void* pa, const void* pb, i
 }
 
 inline int reduce_grid(int64_t M, int R) {
-    int64_t want = (M + (int64_t)R * 4 - 1) / ((int64_t)R * 4);
+    int64_t want = (M + (int64_t)R * 4 - 1) / ((int64_t)R * 4);       // ~4 rows per thread ...
+    int64_t one = (M + R - 1) / R;                                      // ... but small tensors (deep levels) are a latency
+    if (want < 256) want = one < 256 ? one : 256;                       // chain, not a stream: one row per thread then
     if (want < 1) want = 1;
     return (int)(want > MAXBLK ? MAXBLK : want);
 }
