@@ -112,6 +112,11 @@ int mi3d_seg_loss_forward(const float* logits, const int64_t* labels, const floa
 int mi3d_seg_loss_backward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
                            const mi3d_loss_cfg* cfg, const float* coef, const float* grad_out, float* dlogits,
                            void* stream);
+/* The training step needs the loss AND the metrics of the same logits (train_unet.py:224-232): one pass over
+ * logits + labels for both.  metrics_out as mi3d_seg_metrics (device float[3]), workspaces as the two calls. */
+int mi3d_seg_loss_metrics_forward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int D,
+                                  int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out,
+                                  void* loss_workspace, void* metrics_workspace, void* stream);
 size_t mi3d_seg_metrics_workspace_bytes(int C);
 /* out: device float[3] = {iou, dice, accuracy}; D = first spatial dim (reference loop bound, metrics.py:74,101) */
 int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,

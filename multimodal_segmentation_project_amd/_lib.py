@@ -46,6 +46,7 @@ _SIGS = {
     "mi3d_seg_loss_workspace_bytes": (sz, [i32]),
     "mi3d_seg_loss_forward": (i32, [vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, vp]),
     "mi3d_seg_loss_backward": (i32, [vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, vp]),
+    "mi3d_seg_loss_metrics_forward": (i32, [vp, vp, vp, i32, i32, i32, i64, _LP, vp, vp, vp, vp, vp, vp]),
     "mi3d_seg_metrics_workspace_bytes": (sz, [i32]),
     "mi3d_seg_metrics": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp]),
     "mi3d_seg_class_counts": (i32, [vp, vp, i32, i32, i64, vp, vp, vp]),

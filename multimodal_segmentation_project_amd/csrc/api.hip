@@ -27,6 +27,14 @@ int mi3d_seg_loss_forward(const float* logits, const int64_t* labels, const floa
     MI3D_CHECK_ARG(logits && labels && cfg && loss_out && coef && workspace, "mi3d_seg_loss_forward: null pointer");
     return seg_loss_fwd(logits, labels, teacher, N, C, V, to_cfg(cfg), loss_out, coef, workspace, (hipStream_t)stream);
 }
+int mi3d_seg_loss_metrics_forward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int D,
+                                  int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out,
+                                  void* loss_workspace, void* metrics_workspace, void* stream) {
+    MI3D_CHECK_ARG(logits && labels && cfg && loss_out && coef && metrics_out && loss_workspace && metrics_workspace,
+                   "mi3d_seg_loss_metrics_forward: null pointer");
+    return seg_loss_fwd(logits, labels, teacher, N, C, V, to_cfg(cfg), loss_out, coef, loss_workspace, (hipStream_t)stream, D,
+                        metrics_out, metrics_workspace);
+}
 int mi3d_seg_loss_backward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
                            const mi3d_loss_cfg* cfg, const float* coef, const float* grad_out, float* dlogits,
                            void* stream) {

@@ -333,12 +333,19 @@ __device__ __forceinline__ void load_labels(const int64_t* __restrict__ lb, int 
 
 constexpr int NQ = 2 + 3 * MAXC;   // ce, kl, I[c], P[c], T[c]
 
-template <int NC, int VV>
+// METRICS: the same pass also produces the argmax / label count partials of seg_metrics_kernel (the training step needs
+// both on the same logits: one read of logits + labels instead of two)
+template <int NC, int VV, bool METRICS>
 __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                            const float* __restrict__ teacher, int C, int64_t V,
-                                                           float inv_t, double* __restrict__ part) {
+                                                           float inv_t, double* __restrict__ part,
+                                                           unsigned long long* __restrict__ counts) {
     constexpr int NQL = 2 + 3 * NC;
     __shared__ float red[4][NQL];
+    __shared__ unsigned redc[4][3 * NC + 1];
+    unsigned ni[NC], np[NC], nt[NC], nc = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) ni[c] = np[c] = nt[c] = 0;
     int n = blockIdx.y;
     const float* lg = logits + (int64_t)n * C * V;
     const float* tg = teacher ? teacher + (int64_t)n * C * V : nullptr;
@@ -371,6 +378,20 @@ __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restri
                 }
             }
             q[0] += lse - zt;
+            if constexpr (METRICS) {
+                float bvv = z[k][0];
+                int best = 0;
+#pragma unroll
+                for (int c = 1; c < NC; c++)
+                    if (c < C && z[k][c] > bvv) { bvv = z[k][c]; best = c; }
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    ni[c] += (best == c && t[k] == c) ? 1u : 0u;
+                    np[c] += (best == c) ? 1u : 0u;
+                    nt[c] += (t[k] == c) ? 1u : 0u;
+                }
+                nc += (best == t[k]) ? 1u : 0u;
+            }
             if (tg) {
                 float ps[NC], pt[NC], ls, lt;
                 softmax_c<NC>(z[k], C, inv_t, ps, ls);
@@ -397,6 +418,25 @@ __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restri
         double v = 0.0;
         if (src >= 0) v = (double)red[0][src] + (double)red[1][src] + (double)red[2][src] + (double)red[3][src];
         part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NQ + i] = v;
+    }
+    if constexpr (METRICS) {
+        auto wsum = [&](unsigned v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            unsigned a = wsum(ni[c]), b = wsum(np[c]), d = wsum(nt[c]);
+            if (lane == 0) { redc[wave][c] = a; redc[wave][NC + c] = b; redc[wave][2 * NC + c] = d; }
+        }
+        unsigned e = wsum(nc);
+        if (lane == 0) redc[wave][3 * NC] = e;
+        __syncthreads();
+        if (threadIdx.x < 3 * MAXC + 1) {
+            int i = threadIdx.x, src = -1;
+            if (i == 3 * MAXC) src = 3 * NC;
+            else { int k = i / MAXC, c = i % MAXC; if (c < NC) src = k * NC + c; }
+            unsigned long long v = 0;
+            if (src >= 0) v = (unsigned long long)redc[0][src] + redc[1][src] + redc[2][src] + redc[3][src];
+            counts[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (3 * MAXC + 1) + i] = v;
+        }
     }
 }
 
@@ -683,7 +723,7 @@ int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const 
 size_t seg_loss_ws_bytes(int C) { return (size_t)LOSS_MAXBLK * NQ * sizeof(double); }
 
 int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V, LossCfg cfg,
-                 float* loss_out, float* coef, void* ws, hipStream_t s) {
+                 float* loss_out, float* coef, void* ws, hipStream_t s, int D, float* metrics_out, void* metrics_ws) {
     MI3D_CHECK_ARG(C >= 1 && C <= MAXC, "seg_loss: %d classes unsupported (max %d)", C, MAXC);
     MI3D_CHECK_ARG(cfg.w_kd == 0.f || teacher, "seg_loss: distillation weight without teacher logits");
     MI3D_CHECK_ARG(N <= LOSS_MAXBLK, "seg_loss: batch %d > %d unsupported", N, LOSS_MAXBLK);
@@ -692,13 +732,25 @@ int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teache
     int bx = per_sample_blocks(V, v4 ? 4 : 1, N, LOSS_MAXBLK);
     dim3 grid((unsigned)bx, (unsigned)N);
     float it = 1.f / cfg.temp;
-    if (C <= 4 && v4) seg_loss_fwd_kernel<4, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
-    else if (C <= 4) seg_loss_fwd_kernel<4, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
-    else if (v4) seg_loss_fwd_kernel<MAXC, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
-    else seg_loss_fwd_kernel<MAXC, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws);
+    bool met = metrics_out && metrics_ws;
+    unsigned long long* cw = (unsigned long long*)metrics_ws;
+#define SLF(NC_, VV_)                                                                                                      \
+    do {                                                                                                                   \
+        if (met) seg_loss_fwd_kernel<NC_, VV_, true><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws, cw);   \
+        else seg_loss_fwd_kernel<NC_, VV_, false><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws, nullptr); \
+    } while (0)
+    if (C <= 4 && v4) SLF(4, 4);
+    else if (C <= 4) SLF(4, 1);
+    else if (v4) SLF(MAXC, 4);
+    else SLF(MAXC, 1);
+#undef SLF
     MI3D_LAUNCH_CHECK();
     seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, bx * N, N, C, V, cfg, loss_out, coef);
     MI3D_LAUNCH_CHECK();
+    if (met) {
+        seg_metrics_finalize_kernel<<<1, 1024, 0, s>>>(cw, bx * N, N, C, D, V, metrics_out);
+        MI3D_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -138,7 +138,8 @@ enum { MI3D_MAX_CLASSES = 8 };
 size_t seg_loss_ws_bytes(int C);
 // loss_out: device float[1]; coef: device float[2*MI3D_MAX_CLASSES + 4] consumed by seg_loss_bwd
 int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
-                 LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s);
+                 LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s,
+                 int D = 0, float* metrics_out = nullptr, void* metrics_ws = nullptr);
 int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
                  LossCfg cfg, const float* coef, const float* grad_out, float* dlogits, hipStream_t s);
 size_t seg_metrics_ws_bytes(int C);

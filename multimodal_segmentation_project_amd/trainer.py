@@ -188,8 +188,10 @@ class TrainStep:
                  ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], s)
             t_logits = st["t_logits"]
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
-        call("mi3d_seg_loss_forward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
-             ptr(st["metrics"]), ptr(st["coef"]), ptr(st["loss_ws"]), s)
+        # loss + metrics (SURVEY Q1 loop bound D) of the same logits in one pass (replaces 3 argmaxes + 2(D-1) host syncs)
+        call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, desc.D, v,
+             C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
+             ptr(st["met_ws"]), s)
         call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
              ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
         nseg = st["nseg_run"]
@@ -202,9 +204,6 @@ class TrainStep:
                 self._allreduce_bucket(seg)
         if do_comm:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        # metrics on the device, one pass (replaces 3 argmaxes + 2(D-1) host-synchronising loops)
-        call("mi3d_seg_metrics", ptr(st["logits"]), ptr(st["y"]), n, c, desc.D, v, ptr(st["metrics"][1:]),
-             ptr(st["met_ws"]), s)
         if boundary:
             a = self.arena
             rng = st["opt_ranges"]
