@@ -129,11 +129,19 @@ __global__ __launch_bounds__(BLK) void pack_all_kernel(PackJobs J) {
 // SPLITK: blockIdx.z owns a contiguous range of 16-channel input chunks and writes fp32 partial outputs
 // part[kz][voxel][CoutTotal] (no bias / statistics); splitk_finish_kernel sums them.  Used for the deep levels
 // where the spatial tile count alone cannot fill 256 CUs (M = N*V is small, K = 27*Cin is large).
+// virtual block index / grid: the kernel bodies below are __device__ functions so that two of them can share one launch
+// (conv3_bwd_fused_kernel: the input-gradient conv and the weight-gradient of a deep layer are independent and each
+// only a dependent load -> MFMA -> store chain on a few hundred workgroups; run side by side they overlap)
+struct Bid { int x, y, z, gx, gy, gz; };
+__device__ __forceinline__ Bid real_bid() {
+    return Bid{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
+}
+
 template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK>
-__global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
-                                                         const bf16* __restrict__ wp, const float* __restrict__ bias,
-                                                         bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
-                                                         int tilesZ, int tilesY, int tilesX, float* __restrict__ part) {
+__device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict__ x, int xcs, int Cin,
+                                                const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
+                                                int tilesZ, int tilesY, int tilesX, float* __restrict__ part) {
     constexpr int BY = 16 / BX;
     constexpr int TY = TYB * BY, TX = TXB * BX;
     constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
@@ -147,14 +155,14 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
     // CONTIGUOUS run of tiles -> halo voxels shared by neighbouring tiles hit in the same L2 (bijective remap)
     int tile;
     {
-        int nwg = gridDim.x, bid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        int nwg = bid_.gx, bid = bid_.x, q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8, idx = bid / 8;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
     int tx_ = tile % tilesX; tile /= tilesX;
     int ty_ = tile % tilesY; tile /= tilesY;
     int tz_ = tile % tilesZ; int n = tile / tilesZ;
     int z0 = tz_ * TZ, y0 = ty_ * TY, x0 = tx_ * TX;
-    int cobBase = blockIdx.y * COB;
+    int cobBase = bid_.y * COB;
     int nCobTotal = CoutTotal / 16;
 
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -185,8 +193,8 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
     const bf16* xn = x + (int64_t)n * D * H * W * xcs;
     int nchunk = Cin / 16, chunk0 = 0;
     if (SPLITK) {
-        int per = nchunk / gridDim.z;
-        chunk0 = blockIdx.z * per;
+        int per = nchunk / bid_.gz;
+        chunk0 = bid_.z * per;
         nchunk = chunk0 + per;
     }
     bf16x8 sv[NIT];
@@ -270,8 +278,8 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
 
     if constexpr (SPLITK) {
         // fp32 partial tile: part[kz][voxel][CoutTotal], 4 channels (16 B) per lane
-        int64_t Mtot = (int64_t)(gridDim.x / (tilesZ * tilesY * tilesX)) * D * H * W;
-        float* pk = part + (int64_t)blockIdx.z * Mtot * CoutTotal;
+        int64_t Mtot = (int64_t)(bid_.gx / (tilesZ * tilesY * tilesX)) * D * H * W;
+        float* pk = part + (int64_t)bid_.z * Mtot * CoutTotal;
 #pragma unroll
         for (int r = 0; r < MB; r++) {
             int bz = wave, byb = r / TXB, bxb = r % TXB;
@@ -324,9 +332,18 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
             int k = idx & 1, ch = idx >> 1;
             int c = ch / 16, cc = ch % 16;
             float v = red[0][c][cc][k] + red[1][c][cc][k] + red[2][c][cc][k] + red[3][c][cc][k];
-            part[((int64_t)blockIdx.x * 2 + k) * CoutTotal + cobBase * 16 + ch] = v;
+            part[((int64_t)bid_.x * 2 + k) * CoutTotal + cobBase * 16 + ch] = v;
         }
     }
+}
+
+template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK>
+__global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+                                                         const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                         bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
+                                                         int tilesZ, int tilesY, int tilesX, float* __restrict__ part) {
+    conv3_mfma_body<TZ, TYB, TXB, BX, COB, STATS, SPLITK>(real_bid(), x, xcs, Cin, wp, bias, y, ycs, CoutTotal, D, H, W, tilesZ,
+                                                          tilesY, tilesX, part);
 }
 
 // ------------------------------------------------------------------------------------------ persistent variant
@@ -786,17 +803,17 @@ __device__ __forceinline__ void reduce_waves(f32x4 (&acc)[NTILE], float* red, in
 }
 
 template <int CO_B, int CI_B, int NT>
-__global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
-                                                               const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
-                                                               int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
-                                                               float* __restrict__ slabs, Halves xh) {
+__device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restrict__ x, int xcs, int Cin,
+                                                 const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
+                                                 int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
+                                                 float* __restrict__ slabs, Halves xh) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16* dys = reinterpret_cast<bf16*>(lds_raw);                 // [CO_B][WNV][16]
     bf16* xs = dys + CO_B * WNV * 16;                             // [CI_B][WNH][16]
     const char* dysb = reinterpret_cast<const char*>(dys);
     const char* xsb = reinterpret_cast<const char*>(xs);
-    int sb = blockIdx.x / TG, tg = blockIdx.x - sb * TG, nsb = gridDim.x / TG;
-    int co0 = blockIdx.y * CO_B * 16, ci0 = blockIdx.z * CI_B * 16;
+    int sb = bid_.x / TG, tg = bid_.x - sb * TG, nsb = bid_.gx / TG;
+    int co0 = bid_.y * CO_B * 16, ci0 = bid_.z * CI_B * 16;
     int lane = threadIdx.x & 63;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
@@ -813,7 +830,7 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
     float dbs[CO_B];
 #pragma unroll
     for (int a = 0; a < CO_B; a++) dbs[a] = 0.f;
-    bool do_db = (tg == 0 && blockIdx.z == 0);
+    bool do_db = (tg == 0 && bid_.z == 0);
 
     int ntiles = N * tilesZ * tilesY * tilesX;
     constexpr int NA = (CO_B * WNV * 2 + BLK - 1) / BLK, NB = (CI_B * WNH * 2 + BLK - 1) / BLK;
@@ -938,6 +955,40 @@ __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_w
             slab[nW + co0 + threadIdx.x] = (red[(a * 4 + 0) * 16 + c] + red[(a * 4 + 1) * 16 + c]) +
                                            (red[(a * 4 + 2) * 16 + c] + red[(a * 4 + 3) * 16 + c]);
         }
+    }
+}
+
+template <int CO_B, int CI_B, int NT>
+__global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+                                                               const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
+                                                               int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
+                                                               float* __restrict__ slabs, Halves xh) {
+    conv3_wgrad_body<CO_B, CI_B, NT>(real_bid(), x, xcs, Cin, dy, dycs, Cout, N, D, H, W, tilesZ, tilesY, tilesX, TG, slabs, xh);
+}
+
+// Horizontal fusion for the deep levels: workgroups [0, nwg_w) run the weight gradient of a layer, the rest its
+// input-gradient conv (small-geometry tiling, COB = 2, optionally split-K).  Flat 1-D grid, virtual 3-D indices.
+struct FusedArgs {
+    // weight gradient: x = layer input, dy
+    const bf16* wx; int wxcs, wCin; const bf16* wdy; int wdycs, wCout; int tZ, tY, tX; float* slabs; int wgx, wgy, wgz;
+    // input gradient conv: x = dy, packed dgrad weights, y = dx (or split-K partials)
+    const bf16* dxin; int dxcs_in, dCin; const bf16* dwp; bf16* dyout; int dycs_out, dCout; int dtZ, dtY, dtX; float* dpart;
+    int dgx, dgy, dgz;
+    int N, D, H, W;
+};
+template <bool SPLITK>
+__global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_kernel(FusedArgs a) {
+    int nw = a.wgx * a.wgy * a.wgz;
+    int b = blockIdx.x;
+    if (b < nw) {
+        Bid v{b % a.wgx, (b / a.wgx) % a.wgy, b / (a.wgx * a.wgy), a.wgx, a.wgy, a.wgz};
+        conv3_wgrad_body<1, 1, 27>(v, a.wx, a.wxcs, a.wCin, a.wdy, a.wdycs, a.wCout, a.N, a.D, a.H, a.W, a.tZ, a.tY, a.tX, 1, a.slabs,
+                                   Halves());
+    } else {
+        b -= nw;
+        Bid v{b % a.dgx, (b / a.dgx) % a.dgy, b / (a.dgx * a.dgy), a.dgx, a.dgy, a.dgz};
+        conv3_mfma_body<4, 2, 2, 4, 2, false, SPLITK>(v, a.dxin, a.dxcs_in, a.dCin, a.dwp, nullptr, a.dyout, a.dycs_out, a.dCout, a.D, a.H,
+                                                      a.W, a.dtZ, a.dtY, a.dtX, a.dpart);
     }
 }
 
@@ -1265,6 +1316,18 @@ inline int c1_nsb(Geo g) {
 
 }  // namespace
 
+static int wgrad_slab_sum(float* ws, int nsb, int Cin, int Cout, float* dW, float* db, int accumulate, hipStream_t s) {
+    int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
+    if (dW && slab_sz >= (800 << 10))
+        slab_reduce_tile_kernel<<<(Cout / 16) * (Cin / 16) * 4, BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+    else if (slab_sz < (16 << 10))
+        slab_reduce2_kernel<true, 8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+    else
+        slab_reduce2_kernel<true, 32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
 size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g) {
     if (Cin == 1) return (size_t)c1_nsb(g) * ((size_t)Cout * 27 + Cout);
     return (size_t)wgrad_cfg(Cin, Cout, g).nsb * ((size_t)Cout * Cin * 27 + Cout);
@@ -1281,14 +1344,52 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s, xh);
     else { MI3D_CHECK_ARG(false, "conv3_mfma_wgrad: no kernel for this block config"); return -1; }
     MI3D_TRY(rc);
-    if (dW && slab_sz >= (800 << 10))
-        slab_reduce_tile_kernel<<<(Cout / 16) * (Cin / 16) * 4, BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
-    else if (slab_sz < (16 << 10))
-        slab_reduce2_kernel<true, 8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
-    else
-        slab_reduce2_kernel<true, 32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, c.nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+    return wgrad_slab_sum(ws, c.nsb, Cin, Cout, dW, db, accumulate, s);
+}
+
+bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g) {
+    // deep levels only: small-geometry dgrad tiling with two output blocks (Cin % 32), both products on the MFMA path
+    return !big_geo(g) && Cin % 32 == 0 && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && dxcs % 8 == 0 &&
+           !getenv("MI3D_NO_FUSED_BWD");
+}
+
+int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
+                         int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats, float* skws,
+                         hipStream_t s) {
+    MI3D_CHECK_ARG(conv3_mfma_bwd_fused_ok(Cin, Cout, xcs, dycs, dxcs, g) && dx && ((uintptr_t)dx % 16) == 0 && skws,
+                   "conv3_mfma_bwd_fused: unsupported layer %d->%d", Cin, Cout);
+    WgCfg c = wgrad_cfg(Cin, Cout, g);
+    int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
+    MI3D_CHECK_ARG(wgws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_bwd_fused: workspace too small");
+    int ks = pick_ksplit(Cout, Cin, g);                    // dgrad: input channels = Cout, output channels = Cin
+    FusedArgs a;
+    a.wx = (const bf16*)x; a.wxcs = xcs; a.wCin = Cin; a.wdy = (const bf16*)dy; a.wdycs = dycs; a.wCout = Cout;
+    a.tZ = cdiv(g.D, WTZ); a.tY = cdiv(g.H, WTY); a.tX = cdiv(g.W, WTX); a.slabs = wgws;
+    a.wgx = c.nsb; a.wgy = Cout / 16; a.wgz = Cin / 16;
+    a.dxin = (const bf16*)dy; a.dxcs_in = dycs; a.dCin = Cout; a.dwp = (const bf16*)wp_dgrad; a.dyout = (bf16*)dx; a.dycs_out = dxcs;
+    a.dCout = Cin; a.dtZ = cdiv(g.D, 4); a.dtY = cdiv(g.H, 8); a.dtX = cdiv(g.W, 8); a.dpart = ks > 1 ? skws : nullptr;
+    a.dgx = g.N * a.dtZ * a.dtY * a.dtX; a.dgy = Cin / 32; a.dgz = ks;
+    a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
+    size_t lds = (size_t)(WNV + WNH) * 32;
+    if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    unsigned nblk = (unsigned)(a.wgx * a.wgy * a.wgz + a.dgx * a.dgy * a.dgz);
+    if (ks > 1) conv3_bwd_fused_kernel<true><<<nblk, BLK, lds, s>>>(a);
+    else conv3_bwd_fused_kernel<false><<<nblk, BLK, lds, s>>>(a);
     MI3D_LAUNCH_CHECK();
-    return 0;
+    if (ks > 1) {
+        int64_t tot = g.M() * (Cin / 8);
+        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ks, g.M(), Cin, nullptr, (bf16*)dx, dxcs);
+        MI3D_LAUNCH_CHECK();
+    }
+    return wgrad_slab_sum(wgws, c.nsb, Cin, Cout, dW, db, accumulate, s);
 }
 
 // first layer: x fp32 single channel (N,D,H,W), dy bf16 channels-last, Cout % 16 == 0

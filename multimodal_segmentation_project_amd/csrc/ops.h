@@ -56,6 +56,11 @@ size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
                      int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh = Halves());
 
+// deep levels: weight gradient and input-gradient conv of one layer in ONE launch (independent, latency-bound each)
+bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g);
+int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
+                         int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats, float* skws,
+                         hipStream_t s);
 // first layer (Cin = 1, fp32 input) forward on the matrix cores (K = taps); optional BN partial sums like conv3_mfma_fwd
 int conv3_c1_fwd_stat_blocks(Geo g);
 int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,

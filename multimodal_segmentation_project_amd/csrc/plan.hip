@@ -287,6 +287,14 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
                         c.at<float>(p.bnws), c.s));
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
+        void* dx_f = h == 1 ? c.at(p.sC) : dxin;
+        int dxs_f = h == 1 ? H.Cin : dxcs;
+        if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && !(h == 0 && b > p.L && p.planar[B.level]) &&
+            conv3_mfma_bwd_fused_ok(H.Cin, H.Cout, ics, H.Cout, dxs_f, g)) {
+            MI3D_TRY(conv3_mfma_bwd_fused(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx), G(H.pidx + 1),
+                                          accumulate, c.at<float>(p.wgws), p.wgws_floats, c.at<float>(p.skws), c.s));
+            continue;
+        }
         if (G(H.pidx) || G(H.pidx + 1)) {
             hipStream_t ws_ = c.s;
             float* wgws = c.at<float>(p.wgws);
