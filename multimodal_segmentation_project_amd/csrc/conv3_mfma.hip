@@ -137,19 +137,30 @@ __device__ __forceinline__ Bid real_bid() {
     return Bid{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z};
 }
 
-template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK>
+template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK, bool EXT_LDS = false>
 __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict__ x, int xcs, int Cin,
                                                 const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                 bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
-                                                int tilesZ, int tilesY, int tilesX, float* __restrict__ part) {
+                                                int tilesZ, int tilesY, int tilesX, float* __restrict__ part,
+                                                char* ext_lds = nullptr) {
     constexpr int BY = 16 / BX;
     constexpr int TY = TYB * BY, TX = TXB * BX;
     constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
     static_assert(TZ == 4, "one z-slice of the tile per wave");
     constexpr int MB = TYB * TXB;                  // M-blocks per wave (wave w owns z-slice w of the tile)
     constexpr int NVOX = IZ * IY * IX;
-    __shared__ __attribute__((aligned(16))) bf16 xs[NVOX * 16];
-    __shared__ float red[4][COB][16][2];
+    // EXT_LDS: the tile lives in the caller's (dynamic) LDS block -- a fused launch shares one block between the bodies
+    bf16* xs;
+    float (*red)[COB][16][2];
+    if constexpr (EXT_LDS) {
+        xs = reinterpret_cast<bf16*>(ext_lds);
+        red = reinterpret_cast<float (*)[COB][16][2]>(ext_lds + NVOX * 32);
+    } else {
+        __shared__ __attribute__((aligned(16))) bf16 xs_s[NVOX * 16];
+        __shared__ float red_s[4][COB][16][2];
+        xs = xs_s;
+        red = red_s;
+    }
 
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give every XCD a
     // CONTIGUOUS run of tiles -> halo voxels shared by neighbouring tiles hit in the same L2 (bijective remap)
@@ -976,8 +987,9 @@ struct FusedArgs {
     int dgx, dgy, dgz;
     int N, D, H, W;
 };
-template <bool SPLITK>
+template <bool BIG, bool SPLITK>
 __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char fused_lds[];       // one block for either body
     int nw = a.wgx * a.wgy * a.wgz;
     int b = blockIdx.x;
     if (b < nw) {
@@ -987,8 +999,12 @@ __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_kernel(FusedArgs a) {
     } else {
         b -= nw;
         Bid v{b % a.dgx, (b / a.dgx) % a.dgy, b / (a.dgx * a.dgy), a.dgx, a.dgy, a.dgz};
-        conv3_mfma_body<4, 2, 2, 4, 2, false, SPLITK>(v, a.dxin, a.dxcs_in, a.dCin, a.dwp, nullptr, a.dyout, a.dycs_out, a.dCout, a.D, a.H,
-                                                      a.W, a.dtZ, a.dtY, a.dtX, a.dpart);
+        if constexpr (BIG)
+            conv3_mfma_body<4, 8, 1, 16, 2, false, false, true>(v, a.dxin, a.dxcs_in, a.dCin, a.dwp, nullptr, a.dyout, a.dycs_out, a.dCout,
+                                                                a.D, a.H, a.W, a.dtZ, a.dtY, a.dtX, nullptr, fused_lds);
+        else
+            conv3_mfma_body<4, 2, 2, 4, 2, false, SPLITK, true>(v, a.dxin, a.dxcs_in, a.dCin, a.dwp, nullptr, a.dyout, a.dycs_out, a.dCout,
+                                                                a.D, a.H, a.W, a.dtZ, a.dtY, a.dtX, a.dpart, fused_lds);
     }
 }
 
@@ -1348,8 +1364,10 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
 }
 
 bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g) {
-    // deep levels only: small-geometry dgrad tiling with two output blocks (Cin % 32), both products on the MFMA path
-    return !big_geo(g) && Cin % 32 == 0 && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && dxcs % 8 == 0 &&
+    // generic dgrad tilings with two output blocks (Cin % 32) -- not the persistent full-resolution kernels; both
+    // products on the MFMA path
+    if (big_geo(g) && (persist_ok(Cout, Cin, g) || getenv("MI3D_NO_FUSED_BWD_BIG"))) return false;
+    return Cin % 32 == 0 && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && dxcs % 8 == 0 &&
            !getenv("MI3D_NO_FUSED_BWD");
 }
 
@@ -1361,28 +1379,32 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     WgCfg c = wgrad_cfg(Cin, Cout, g);
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
     MI3D_CHECK_ARG(wgws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_bwd_fused: workspace too small");
-    int ks = pick_ksplit(Cout, Cin, g);                    // dgrad: input channels = Cout, output channels = Cin
+    bool big = big_geo(g);
+    int ks = pick_ksplit(Cout, Cin, g);                    // dgrad: input channels = Cout, output channels = Cin (1 if big)
     FusedArgs a;
     a.wx = (const bf16*)x; a.wxcs = xcs; a.wCin = Cin; a.wdy = (const bf16*)dy; a.wdycs = dycs; a.wCout = Cout;
     a.tZ = cdiv(g.D, WTZ); a.tY = cdiv(g.H, WTY); a.tX = cdiv(g.W, WTX); a.slabs = wgws;
     a.wgx = c.nsb; a.wgy = Cout / 16; a.wgz = Cin / 16;
     a.dxin = (const bf16*)dy; a.dxcs_in = dycs; a.dCin = Cout; a.dwp = (const bf16*)wp_dgrad; a.dyout = (bf16*)dx; a.dycs_out = dxcs;
-    a.dCout = Cin; a.dtZ = cdiv(g.D, 4); a.dtY = cdiv(g.H, 8); a.dtX = cdiv(g.W, 8); a.dpart = ks > 1 ? skws : nullptr;
+    a.dCout = Cin; a.dtZ = cdiv(g.D, 4); a.dtY = cdiv(g.H, 8); a.dtX = cdiv(g.W, big ? 16 : 8); a.dpart = ks > 1 ? skws : nullptr;
     a.dgx = g.N * a.dtZ * a.dtY * a.dtX; a.dgy = Cin / 32; a.dgz = ks;
     a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
     size_t lds = (size_t)(WNV + WNH) * 32;
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
     static bool attr_set = false;
     if (!attr_set) {
-        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<true>),
+        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<false, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<false>),
+        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<false, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<true, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     unsigned nblk = (unsigned)(a.wgx * a.wgy * a.wgz + a.dgx * a.dgy * a.dgz);
-    if (ks > 1) conv3_bwd_fused_kernel<true><<<nblk, BLK, lds, s>>>(a);
-    else conv3_bwd_fused_kernel<false><<<nblk, BLK, lds, s>>>(a);
+    if (big) conv3_bwd_fused_kernel<true, false><<<nblk, BLK, lds, s>>>(a);
+    else if (ks > 1) conv3_bwd_fused_kernel<false, true><<<nblk, BLK, lds, s>>>(a);
+    else conv3_bwd_fused_kernel<false, false><<<nblk, BLK, lds, s>>>(a);
     MI3D_LAUNCH_CHECK();
     if (ks > 1) {
         int64_t tot = g.M() * (Cin / 8);
