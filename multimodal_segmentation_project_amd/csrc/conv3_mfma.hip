@@ -366,12 +366,12 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
 //   * interior tiles take a check-free staging path (one add per 16-B piece); only border tiles test coordinates;
 //   * the next tile's (or chunk's) global loads are issued before the MFMA loop of the current one (T14 split);
 //   * BatchNorm partial sums accumulate in registers across tiles -> ONE partial row per workgroup.
-template <int COB, int NCH, bool STATS>
-__global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* __restrict__ x, int xcs,
-                                                                    const bf16* __restrict__ wp, const float* __restrict__ bias,
-                                                                    bf16* __restrict__ y, int ycs, int D, int H, int W,
-                                                                    int tilesZ, int tilesY, int tilesX, int ntiles,
-                                                                    float* __restrict__ part, Halves xh, Halves yh) {
+template <int COB, int NCH, bool STATS, bool EXT_LDS = false>
+__device__ __forceinline__ void conv3_mfma_persist_body(Bid bid_, const bf16* __restrict__ x, int xcs,
+                                                        const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                        bf16* __restrict__ y, int ycs, int D, int H, int W,
+                                                        int tilesZ, int tilesY, int tilesX, int ntiles,
+                                                        float* __restrict__ part, Halves xh, Halves yh, char* ext_lds = nullptr) {
     constexpr int TZ = 4, TY = 8, TX = 16, IZ = 6, IY = 10, IX = 18, MB = 8;
     constexpr int NVOX = IZ * IY * IX, NIT = (NVOX * 2 + BLK - 1) / BLK;
     constexpr int CoutTotal = COB * 16;
@@ -379,9 +379,18 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
     // workgroups still fit per CU (registers AND LDS)
     constexpr bool WLDS = true;      // registers go to the F/G row fragments; weights (14-28 KB) live in LDS
     constexpr int NWF = NCH * 14 * COB;
-    __shared__ __attribute__((aligned(16))) bf16 xs[NVOX * 16];
-    __shared__ __attribute__((aligned(16))) bf16 wl[WLDS ? NWF * 512 : 8];
-    __shared__ float red[4][COB][16][2];
+    bf16* xs; bf16* wl;
+    float (*red)[COB][16][2];
+    if constexpr (EXT_LDS) {              // fused launch: one dynamic LDS block shared with the other body
+        xs = reinterpret_cast<bf16*>(ext_lds);
+        wl = xs + NVOX * 16;
+        red = reinterpret_cast<float (*)[COB][16][2]>(ext_lds + (NVOX * 16 + NWF * 512) * 2);
+    } else {
+        __shared__ __attribute__((aligned(16))) bf16 xs_s[NVOX * 16];
+        __shared__ __attribute__((aligned(16))) bf16 wl_s[WLDS ? NWF * 512 : 8];
+        __shared__ float red_s[4][COB][16][2];
+        xs = xs_s; wl = wl_s; red = red_s;
+    }
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int vn = lane & 15, g = lane >> 4;
     int laneOff = ((vn * 16 + (g & 1) * 8) * 2) + wave * (IY * IX * 32);
@@ -472,11 +481,11 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
     // the halo voxels neighbouring tiles share are served by that XCD's L2 instead of the fabric (bijective remap)
     int tile;
     {
-        int nwg = gridDim.x, bid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        int nwg = bid_.gx, bid = bid_.x, q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8, idx = bid / 8;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
     if (tile < ntiles) load_pieces(tile, 0);
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < ntiles; tile += bid_.gx) {
         f32x4 acc[MB][COB];
 #pragma unroll
         for (int r = 0; r < MB; r++)
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
             }
             __syncthreads();
             if (ch + 1 < NCH) load_pieces(tile, ch + 1);
-            else if (tile + (int)gridDim.x < ntiles) load_pieces(tile + gridDim.x, 0);
+            else if (tile + bid_.gx < ntiles) load_pieces(tile + bid_.gx, 0);
             // K loop with LDS-row reuse (ktap mode 1).  For a fixed dz the three K-steps (dz,dy,dx0|dx1), dy = 0..2, of
             // M-block row y read halo row y+dy: 10 row fragments F[0..9] feed 24 MFMAs (2.4x fewer ds_read_b128); the
             // dx = 2 taps pair up over dy (G), the last two K-steps over dz.  70 instead of 112 LDS reads per chunk.
@@ -596,9 +605,18 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
             int k = idx & 1, chn = idx >> 1;
             int c = chn / 16, cc = chn % 16;
             float v = (red[0][c][cc][k] + red[1][c][cc][k]) + (red[2][c][cc][k] + red[3][c][cc][k]);
-            part[((int64_t)blockIdx.x * 2 + k) * CoutTotal + chn] = v;
+            part[((int64_t)bid_.x * 2 + k) * CoutTotal + chn] = v;
         }
     }
+}
+
+template <int COB, int NCH, bool STATS>
+__global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* __restrict__ x, int xcs,
+                                                                    const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                                    bf16* __restrict__ y, int ycs, int D, int H, int W,
+                                                                    int tilesZ, int tilesY, int tilesX, int ntiles,
+                                                                    float* __restrict__ part, Halves xh, Halves yh) {
+    conv3_mfma_persist_body<COB, NCH, STATS>(real_bid(), x, xcs, wp, bias, y, ycs, D, H, W, tilesZ, tilesY, tilesX, ntiles, part, xh, yh);
 }
 
 constexpr int PERSIST_WGS = 512;
@@ -987,6 +1005,34 @@ struct FusedArgs {
     int dgx, dgy, dgz;
     int N, D, H, W;
 };
+// Full-resolution variant: the input-gradient conv is the persistent kernel body.  Both halves are persistent with ONE
+// workgroup per CU each, so every CU runs one MFMA-heavy dgrad workgroup beside one staging/LDS-heavy wgrad workgroup
+// for the whole launch (two workgroups of the same kind contend for the same unit in the same phase).
+struct FusedPArgs {
+    const bf16* wx; int wxcs, wCin; const bf16* wdy; int wdycs, wCout; int tZ, tY, tX; float* slabs; int wgx, wgy, wgz; Halves wxh;
+    const bf16* dxin; int dxcs_in; const bf16* dwp; bf16* dyout; int dycs_out; int ptZ, ptY, ptX, pnt, pgrid; Halves dyh;
+    int N, D, H, W;
+};
+template <int COB, int NCH>
+__global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_persist_kernel(FusedPArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char fusedp_lds[];
+    int nw = a.wgx * a.wgy * a.wgz;
+    int b = blockIdx.x;
+    // interleave the two kinds so that consecutive (same-CU) workgroup slots get one of each
+    bool is_w = (b & 1) == 0;           // even slots: weight gradient, odd slots: input gradient (surplus slots idle)
+    int idx = b >> 1;
+    if (is_w) {
+        if (idx >= nw) return;
+        Bid v{idx % a.wgx, (idx / a.wgx) % a.wgy, idx / (a.wgx * a.wgy), a.wgx, a.wgy, a.wgz};
+        conv3_wgrad_body<1, 1, 27>(v, a.wx, a.wxcs, a.wCin, a.wdy, a.wdycs, a.wCout, a.N, a.D, a.H, a.W, a.tZ, a.tY, a.tX, 1, a.slabs, a.wxh);
+    } else {
+        if (idx >= a.pgrid) return;
+        Bid v{idx, 0, 0, a.pgrid, 1, 1};
+        conv3_mfma_persist_body<COB, NCH, false, true>(v, a.dxin, a.dxcs_in, a.dwp, nullptr, a.dyout, a.dycs_out, a.D, a.H, a.W, a.ptZ, a.ptY,
+                                                       a.ptX, a.pnt, nullptr, Halves(), a.dyh, fusedp_lds);
+    }
+}
+
 template <bool BIG, bool SPLITK>
 __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char fused_lds[];       // one block for either body
@@ -1361,6 +1407,56 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     else { MI3D_CHECK_ARG(false, "conv3_mfma_wgrad: no kernel for this block config"); return -1; }
     MI3D_TRY(rc);
     return wgrad_slab_sum(ws, c.nsb, Cin, Cout, dW, db, accumulate, s);
+}
+
+// full-resolution layers: dgrad on the persistent body (Cout -> Cin must be one of its shapes)
+bool conv3_mfma_bwd_fused_persist_ok(int Cin, int Cout, int xcs, int dycs, Geo g) {
+    return persist_ok(Cout, Cin, g) && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && !getenv("MI3D_NO_FUSED_BWD") &&
+           !getenv("MI3D_NO_FUSED_BWD_P");
+}
+int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
+                                 int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats,
+                                 hipStream_t s, Halves xh, Halves dxh) {
+    MI3D_CHECK_ARG(conv3_mfma_bwd_fused_persist_ok(Cin, Cout, xcs, dycs, g) && dx, "conv3_mfma_bwd_fused_persist: unsupported layer");
+    int groups = (Cout / 16) * (Cin / 16);
+    int64_t ntw = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
+    const int wcap = 256, pcap = 256;          // one workgroup of each kind per CU (512 + 512 = no co-residency: measured equal to unfused)
+    int64_t want = wcap / groups; if (want < 1) want = 1;
+    int64_t rounds = cdiv(ntw, want);
+    int nsb = (int)cdiv(ntw, rounds);
+    int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
+    MI3D_CHECK_ARG(wgws_floats >= (size_t)nsb * slab_sz, "conv3_mfma_bwd_fused_persist: workspace too small");
+    FusedPArgs a;
+    a.wx = (const bf16*)x; a.wxcs = xcs; a.wCin = Cin; a.wdy = (const bf16*)dy; a.wdycs = dycs; a.wCout = Cout;
+    a.tZ = cdiv(g.D, WTZ); a.tY = cdiv(g.H, WTY); a.tX = cdiv(g.W, WTX); a.slabs = wgws;
+    a.wgx = nsb; a.wgy = Cout / 16; a.wgz = Cin / 16; a.wxh = xh;
+    a.dxin = (const bf16*)dy; a.dxcs_in = dycs; a.dwp = (const bf16*)wp_dgrad; a.dyout = (bf16*)dx; a.dycs_out = dxcs;
+    a.ptZ = cdiv(g.D, 4); a.ptY = cdiv(g.H, 8); a.ptX = cdiv(g.W, 16); a.pnt = g.N * a.ptZ * a.ptY * a.ptX;
+    a.pgrid = a.pnt < pcap ? a.pnt : pcap; a.dyh = dxh;
+    a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
+    int nw = a.wgx * a.wgy * a.wgz;
+    int half = nw > a.pgrid ? nw : a.pgrid;
+    unsigned nblk = (unsigned)(2 * half);
+    // dgrad conv Cout -> Cin: persistent shapes (16,16): <1,1>, (32->16): <1,2>, (16->32): <2,1>
+    size_t ldsw = (size_t)(WNV + WNH) * 32;
+#define FP(COB_, NCH_)                                                                                                        \
+    do {                                                                                                                      \
+        size_t ldsp = (size_t)(6 * 10 * 18 * 16 + NCH_ * 14 * COB_ * 512) * 2 + 4 * COB_ * 16 * 2 * 4;                        \
+        size_t lds = ldsp > ldsw ? ldsp : ldsw;                                                                               \
+        static bool set_ = false;                                                                                             \
+        if (!set_) {                                                                                                          \
+            MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_persist_kernel<COB_, NCH_>),          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+            set_ = true;                                                                                                      \
+        }                                                                                                                     \
+        conv3_bwd_fused_persist_kernel<COB_, NCH_><<<nblk, BLK, lds, s>>>(a);                                                   \
+    } while (0)
+    if (Cout == 16 && Cin == 16) FP(1, 1);
+    else if (Cout == 32) FP(1, 2);
+    else FP(2, 1);
+#undef FP
+    MI3D_LAUNCH_CHECK();
+    return wgrad_slab_sum(wgws, nsb, Cin, Cout, dW, db, accumulate, s);
 }
 
 bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g) {

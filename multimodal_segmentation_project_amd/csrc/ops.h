@@ -61,6 +61,10 @@ bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo
 int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                          int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats, float* skws,
                          hipStream_t s);
+bool conv3_mfma_bwd_fused_persist_ok(int Cin, int Cout, int xcs, int dycs, Geo g);
+int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
+                                 int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats,
+                                 hipStream_t s, Halves xh = Halves(), Halves dxh = Halves());
 // first layer (Cin = 1, fp32 input) forward on the matrix cores (K = taps); optional BN partial sums like conv3_mfma_fwd
 int conv3_c1_fwd_stat_blocks(Geo g);
 int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,

@@ -289,6 +289,12 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
         void* dx_f = h == 1 ? c.at(p.sC) : dxin;
         int dxs_f = h == 1 ? H.Cin : dxcs;
+        if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && conv3_mfma_bwd_fused_persist_ok(H.Cin, H.Cout, ics, H.Cout, g)) {
+            Halves hv = (h == 0 && b > p.L) ? p.halves(B.level) : Halves();
+            MI3D_TRY(conv3_mfma_bwd_fused_persist(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx),
+                                                  G(H.pidx + 1), accumulate, c.at<float>(p.wgws), p.wgws_floats, c.s, hv, hv));
+            continue;
+        }
         if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && !(h == 0 && b > p.L && p.planar[B.level]) &&
             conv3_mfma_bwd_fused_ok(H.Cin, H.Cout, ics, H.Cout, dxs_f, g)) {
             MI3D_TRY(conv3_mfma_bwd_fused(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx), G(H.pidx + 1),
