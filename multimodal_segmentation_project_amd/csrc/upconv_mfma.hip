@@ -95,15 +95,16 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------ backward data
+struct UBid { int x, y, z, gx, gy; };        // virtual block index / grid (bodies shared with the fused launch below)
 template <int S>   // S = 8*Cout/32 K-steps
-__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* __restrict__ g, int gcs, int Cout,
-                                                                   const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
-                                                                   int Cin, int N, int D, int H, int W) {
+__device__ __forceinline__ void upconv_mfma_bwd_data_body(UBid bid_, const bf16* __restrict__ g, int gcs, int Cout,
+                                                          const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
+                                                          int Cin, int N, int D, int H, int W) {
     int64_t M = (int64_t)N * D * H * W;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, vn = lane & 15, G = lane >> 4;
     int CIBN = Cin / 16;
     int64_t ngroups = (M + 15) / 16;
-    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    for (int64_t grp = (int64_t)bid_.x * 4 + wave; grp < ngroups; grp += (int64_t)bid_.gx * 4) {
         int64_t v = grp * 16 + vn;
         bool ok = v < M;
         int64_t vc = ok ? v : M - 1;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* _
             int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
             Bf[s] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0);
         }
-        for (int cib = blockIdx.y; cib < CIBN; cib += gridDim.y) {
+        for (int cib = bid_.y; cib < CIBN; cib += bid_.gy) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const bf16* wp = wb + ((int64_t)cib * S) * 512 + lane * 8;
 #pragma unroll
@@ -127,19 +128,26 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* _
     }
 }
 
+template <int S>
+__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_kernel(const bf16* __restrict__ g, int gcs, int Cout,
+                                                                   const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
+                                                                   int Cin, int N, int D, int H, int W) {
+    upconv_mfma_bwd_data_body<S>(UBid{(int)blockIdx.x, (int)blockIdx.y, 0, (int)gridDim.x, (int)gridDim.y}, g, gcs, Cout, wb, dx, dxcs,
+                                 Cin, N, D, H, W);
+}
+
 // Few voxels, many K-steps (deep levels): one workgroup per 16-voxel group and channel block; the S K-steps are split
 // over the 4 waves (each loads S/4 gathered fragments + S/4 weight fragments) and summed through LDS -> the dependent
 // load -> MFMA chain is 4x shorter and there are 4x more workgroups.
 template <int S>
-__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_ks_kernel(const bf16* __restrict__ g, int gcs, int Cout,
-                                                                      const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
-                                                                      int Cin, int N, int D, int H, int W) {
+__device__ __forceinline__ void upconv_mfma_bwd_data_ks_body(UBid bid_, float (*red)[64][4], const bf16* __restrict__ g, int gcs, int Cout,
+                                                             const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
+                                                             int Cin, int N, int D, int H, int W) {
     static_assert(S % 4 == 0, "K-steps split over 4 waves");
     constexpr int SW = S / 4;
-    __shared__ float red[4][64][4];
     int64_t M = (int64_t)N * D * H * W;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, vn = lane & 15, G = lane >> 4;
-    int64_t v = (int64_t)blockIdx.x * 16 + vn;
+    int64_t v = (int64_t)bid_.x * 16 + vn;
     bool ok = v < M;
     int64_t vc = ok ? v : M - 1;
     unsigned vu = (unsigned)vc; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_ks_kernel(const bf16
         int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
         Bf[i] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0);
     }
-    int cib = blockIdx.y;
+    int cib = bid_.y;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16* wp = wb + ((int64_t)cib * S + wave * SW) * 512 + lane * 8;
 #pragma unroll
@@ -168,6 +176,15 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_ks_kernel(const bf16
         bf16x4 o = {(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
         if (ok) *reinterpret_cast<bf16x4*>(dx + v * dxcs + cib * 16 + 4 * G) = o;
     }
+}
+
+template <int S>
+__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_data_ks_kernel(const bf16* __restrict__ g, int gcs, int Cout,
+                                                                      const bf16* __restrict__ wb, bf16* __restrict__ dx, int dxcs,
+                                                                      int Cin, int N, int D, int H, int W) {
+    __shared__ float red[4][64][4];
+    upconv_mfma_bwd_data_ks_body<S>(UBid{(int)blockIdx.x, (int)blockIdx.y, 0, (int)gridDim.x, (int)gridDim.y}, red, g, gcs, Cout, wb, dx,
+                                    dxcs, Cin, N, D, H, W);
 }
 
 // ---------------------------------------------------------------------------------------- backward weight
@@ -191,15 +208,15 @@ __device__ __forceinline__ void reduce_waves32(f32x4 (&acc)[32], float* red, int
 }
 
 // workgroup = 2 ci-blocks x 2 co-blocks x 8 taps = 32 accumulator tiles; x tile [2][UV][16], g tile [2][8][UV][16]
-__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16* __restrict__ x, int xcs, int Cin,
-                                                                     const bf16* __restrict__ g, int gcs, int Cout, int N,
-                                                                     int D, int H, int W, float* __restrict__ slabs) {
+__device__ __forceinline__ void upconv_mfma_bwd_weight_body(UBid bid_, const bf16* __restrict__ x, int xcs, int Cin,
+                                                            const bf16* __restrict__ g, int gcs, int Cout, int N,
+                                                            int D, int H, int W, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16* xs = reinterpret_cast<bf16*>(lds_raw);            // [2][UV][16]
     bf16* gs = xs + 2 * UV * 16;                            // [2][8][UV][16]
     const char* xsb = reinterpret_cast<const char*>(xs);
     const char* gsb = reinterpret_cast<const char*>(gs);
-    int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    int ci0 = bid_.y * 32, co0 = bid_.z * 32;
     int cbn = (Cout - co0) >= 32 ? 2 : 1;                   // Cout = 16 -> one co block (second plane zero)
     int lane = threadIdx.x & 63;
     int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -236,15 +253,15 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
         }
     };
     // the next tile's global loads are issued before this tile's MFMAs (register prefetch)
-    if ((int64_t)blockIdx.x < ntile) load_tile(blockIdx.x);
-    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    if ((int64_t)bid_.x < ntile) load_tile(bid_.x);
+    for (int64_t tile = bid_.x; tile < ntile; tile += bid_.gx) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NA; it++) *reinterpret_cast<bf16x8*>(xs + (threadIdx.x + it * BLK) * 8) = va[it];
 #pragma unroll
         for (int it = 0; it < NB; it++) *reinterpret_cast<bf16x8*>(gs + (threadIdx.x + it * BLK) * 8) = vb[it];
         __syncthreads();
-        if (tile + gridDim.x < ntile) load_tile(tile + gridDim.x);
+        if (tile + bid_.gx < ntile) load_tile(tile + bid_.gx);
         bf16x8 A[2];
 #pragma unroll
         for (int a = 0; a < 2; a++) A[a] = tr_frag(xsb, laneK + a * (UV * 32));
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
 #pragma unroll
             for (int tap = 0; tap < 8; tap++) {
                 bf16x8 B = tr_frag(gsb, laneK + (cb * 8 + tap) * (UV * 32));
-                if (blockIdx.y == 0) {
+                if (bid_.y == 0) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) dbs[cb] += (float)B[j];
                 }
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
             }
     }
     int64_t nW = (int64_t)Cin * Cout * 8;
-    float* slab = slabs + (int64_t)blockIdx.x * (nW + Cout);
+    float* slab = slabs + (int64_t)bid_.x * (nW + Cout);
     float* red = reinterpret_cast<float*>(lds_raw);
     reduce_waves32(acc, red, wave, lane, [&](int idx, f32x4 sum) {
         int tap = idx % 8, cb = (idx / 8) % 2, a = idx / 16;
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
             }
         }
     });
-    if (blockIdx.y == 0) {
+    if (bid_.y == 0) {
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < 2; cb++) {
@@ -288,6 +305,45 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
             int cb = threadIdx.x / 16, c = threadIdx.x % 16;
             slab[nW + co0 + threadIdx.x] = (red[(cb * 4 + 0) * 16 + c] + red[(cb * 4 + 1) * 16 + c]) +
                                            (red[(cb * 4 + 2) * 16 + c] + red[(cb * 4 + 3) * 16 + c]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+                                                                     const bf16* __restrict__ g, int gcs, int Cout, int N,
+                                                                     int D, int H, int W, float* __restrict__ slabs) {
+    upconv_mfma_bwd_weight_body(UBid{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y}, x, xcs, Cin, g,
+                                gcs, Cout, N, D, H, W, slabs);
+}
+
+// Input gradient and weight gradient of a transposed conv are independent: one launch, weight-gradient workgroups first
+// (they are the longer ones), data-gradient workgroups behind them on a flat grid.
+struct UFusedArgs {
+    const bf16* x; int xcs, Cin; const bf16* g; int gcs, Cout; const bf16* wb; bf16* dx; int dxcs; float* slabs;
+    int N, D, H, W; int wgx, wgy, wgz, dgx, dgy;
+};
+template <int S, bool KSPLIT>
+__global__ __launch_bounds__(BLK) void upconv_mfma_bwd_fused_kernel(UFusedArgs a) {
+    int nw = a.wgx * a.wgy * a.wgz, nd = a.dgx * a.dgy;
+    // interleave the two kinds (even slots: weight gradient, odd: data gradient) while both last, so that a CU holds
+    // one of each; the surplus of the longer list follows
+    int b = blockIdx.x, m = nw < nd ? nw : nd;
+    bool is_w; int idx;
+    if (b < 2 * m) { is_w = (b & 1) == 0; idx = b >> 1; }
+    else { is_w = nw > nd; idx = m + (b - 2 * m); }
+    if (is_w) {
+        b = idx;
+        upconv_mfma_bwd_weight_body(UBid{b % a.wgx, (b / a.wgx) % a.wgy, b / (a.wgx * a.wgy), a.wgx, a.wgy}, a.x, a.xcs, a.Cin, a.g,
+                                    a.gcs, a.Cout, a.N, a.D, a.H, a.W, a.slabs);
+    } else {
+        b = idx;
+        UBid v{b % a.dgx, b / a.dgx, 0, a.dgx, a.dgy};
+        if constexpr (KSPLIT) {
+            extern __shared__ __attribute__((aligned(16))) char uf_lds[];
+            upconv_mfma_bwd_data_ks_body<S>(v, reinterpret_cast<float (*)[64][4]>(uf_lds), a.g, a.gcs, a.Cout, a.wb, a.dx, a.dxcs, a.Cin,
+                                            a.N, a.D, a.H, a.W);
+        } else {
+            upconv_mfma_bwd_data_body<S>(v, a.g, a.gcs, a.Cout, a.wb, a.dx, a.dxcs, a.Cin, a.N, a.D, a.H, a.W);
         }
     }
 }
@@ -370,6 +426,47 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
     MI3D_CHECK_ARG(g.M() < (1ll << 31), "upconv2_mfma_bwd: more than 2^31 input voxels");
     const bf16* xp = (const bf16*)x; const bf16* gp = (const bf16*)gy;
     const bf16* wb = (const bf16*)wp + (size_t)Cin * Cout * 8;
+    if (dx && (dW || db) && !getenv("MI3D_NO_FUSED_UPBWD")) {
+        int gx = wave_grid(g.M());
+        int gy = 1;
+        while (gx * gy < 512 && gy < Cin / 16) gy *= 2;
+        int64_t gkx = cdiv(g.M(), 16);
+        bool ksp = gx * gy < 512 && Cout / 4 >= 8 && gkx * (Cin / 16) <= 8192;
+        const int wcap = 256, dcap = 256;                    // one workgroup of each kind per CU (measured best)
+        int groups = (Cin / 32) * (int)cdiv(Cout, 32);
+        int64_t ntile = (g.M() + UV - 1) / UV;
+        int64_t want = cdiv((int64_t)wcap, (int64_t)groups);
+        int nsb = (int)(ntile < want ? ntile : want);
+        int64_t nW = (int64_t)Cin * Cout * 8, slab_sz = nW + Cout;
+        MI3D_CHECK_ARG(ws_floats >= (size_t)nsb * slab_sz, "upconv2_mfma_bwd: workspace too small");
+        if (!ksp && gx * gy > dcap) gx = dcap / gy < 1 ? 1 : dcap / gy;          // persistent data-gradient workgroups
+        UFusedArgs a{xp, xcs, Cin, gp, gycs, Cout, wb, (bf16*)dx, dxcs, ws, g.N, g.D, g.H, g.W,
+                     nsb, Cin / 32, (int)cdiv(Cout, 32), ksp ? (int)gkx : gx, ksp ? Cin / 16 : gy};
+        size_t lds = (size_t)(2 * UV + 16 * UV) * 32;
+        unsigned nblk = (unsigned)(a.wgx * a.wgy * a.wgz + a.dgx * a.dgy);
+#define UFL(SS, KS_)                                                                                                          \
+        do {                                                                                                                  \
+            static bool set_ = false;                                                                                         \
+            if (!set_) {                                                                                                      \
+                MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_mfma_bwd_fused_kernel<SS, KS_>),           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+                set_ = true;                                                                                                  \
+            }                                                                                                                 \
+            upconv_mfma_bwd_fused_kernel<SS, KS_><<<nblk, BLK, lds, s>>>(a);                                                    \
+        } while (0)
+        switch (Cout / 4) {
+            case 4: UFL(4, false); break;
+            case 8: if (ksp) UFL(8, true); else UFL(8, false); break;
+            case 16: if (ksp) UFL(16, true); else UFL(16, false); break;
+            default: if (ksp) UFL(32, true); else UFL(32, false); break;
+        }
+#undef UFL
+        MI3D_LAUNCH_CHECK();
+        if (slab_sz < (16 << 10)) slab_reduce3_kernel<8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
+        else slab_reduce3_kernel<32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
+        MI3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (dx) {
         int gx = wave_grid(g.M());
         int gy = 1;
