@@ -321,3 +321,31 @@ def test_reference_volume_shape_192():
     c, _ = one(torch.float32)
     assert abs(float(a[0]) - float(c[0])) < 5e-3 * abs(float(c[0]))          # loss
     assert abs(float(a[2]) - float(c[2])) < 1e-3                               # Dice
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_learnable_run_converges(dtype):
+    """SURVEY §8(d) learnable parity run: blocky labels, image = label/3 + 0.1*noise.  The whole step (forward, Dice/CE,
+    backward, fused AdamW, BN running statistics) must actually train: loss falls, train Dice and eval-mode Dice > 0.9."""
+    import multimodal_segmentation_project_amd as mi
+    from multimodal_segmentation_project_amd.trainer import TrainStep
+    dev = torch.device("cuda")
+    S = 32
+    g = torch.Generator().manual_seed(7)
+    idx = torch.arange(S) // (S // 4)
+    lab = ((idx[:, None, None] + idx[None, :, None] + idx[None, None, :]) % 4).to(torch.int64)
+    y = lab[None, None].repeat(2, 1, 1, 1, 1).contiguous()
+    x = (y.float() / 3 + 0.1 * torch.randn(2, 1, S, S, S, generator=g)).contiguous()
+    x, y = x.to(dev), y.to(dev)
+    torch.manual_seed(0)
+    m = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).train()
+    ts = TrainStep(m, loss="combined", lr=3e-3, weight_decay=0.01, compute_dtype=dtype, use_graph=True)
+    ts.load_batch(x, y)
+    hist = [ts.step_static().cpu().clone() for _ in range(60)]
+    first, last = hist[0], hist[-1]
+    assert all(torch.isfinite(h).all() for h in hist)
+    assert float(last[0]) < 0.35 * float(first[0]), (first, last)
+    assert float(last[2]) > 0.9, last                                   # train-mode Dice
+    ev = ts.evaluate(x, y).cpu()
+    assert float(ev[2]) > 0.9, ev                                       # eval mode: BN running statistics are usable
