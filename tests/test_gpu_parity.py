@@ -473,6 +473,15 @@ def test_layout_and_kernel_choices_are_invisible(monkeypatch):
     assert l0 == l1 and torch.equal(o0, o1)
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
+    # fused backward launches (dgrad + wgrad, upconv data + weight gradient) off: same kernels bodies, only the
+    # weight-gradient slab partition (summation order) changes
+    monkeypatch.setenv("MI3D_NO_FUSED_BWD", "1")
+    monkeypatch.setenv("MI3D_NO_FUSED_UPBWD", "1")
+    l3, o3, g3 = run()
+    assert l3 == l0 and torch.equal(o3, o0)
+    va = torch.cat([a.flatten() for a in g0]).cpu()
+    vb = torch.cat([b.flatten() for b in g3]).cpu()
+    assert relerr(vb, va) < 1e-3
     monkeypatch.setenv("MI3D_NO_PERSIST", "1")          # generic one-tile-per-workgroup kernels everywhere
     l2, o2, g2 = run()
     assert abs(l2 - l0) < 2e-3 * abs(l0)
