@@ -15,6 +15,7 @@ namespace {
 
 constexpr int BLK = 256;
 constexpr int MAXBLK = 1024;
+constexpr int FIN_T = 256;          // threads per channel in the finalize kernels
 
 struct RowMap {
     int G;   // channel groups per row (C / VEC)
@@ -106,15 +107,22 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
                                          const float* gamma, const float* beta, float* running_mean,
                                          float* running_var, int64_t* nbt, float momentum, float eps,
                                          float* stat) {
+    // FIN_T threads per channel: lane-strided double sums, wave tree, then the waves in fixed order
+    __shared__ double ws_[FIN_T / 64][2];
     int c = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
+    for (int b = lane; b < nblk; b += FIN_T) {
         s += (double)part[((size_t)b * 2 + 0) * C + c];
         q += (double)part[((size_t)b * 2 + 1) * C + c];
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
+    if ((lane & 63) == 0) { ws_[lane >> 6][0] = s; ws_[lane >> 6][1] = q; }
+    __syncthreads();
     if (lane == 0) {
+        s = 0.0; q = 0.0;
+#pragma unroll
+        for (int w = 0; w < FIN_T / 64; w++) { s += ws_[w][0]; q += ws_[w][1]; }
         double mean = s / (double)M;
         double var = q / (double)M - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -210,15 +218,21 @@ __global__ __launch_bounds__(BLK) void bn_bwd_reduce_kernel(const T* __restrict_
 // coef[3][C] = {c1 = sum_dyh / M, c2 = sum_dyh_xhat / M, g = gamma*invstd(=a)}; dgamma, dbeta (+)=
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, int64_t M,
                                        const float* stat, float* dgamma, float* dbeta, int accumulate, float* coef) {
+    __shared__ double ws_[FIN_T / 64][2];
     int c = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
+    for (int b = lane; b < nblk; b += FIN_T) {
         s += (double)part[((size_t)b * 2 + 0) * C + c];
         q += (double)part[((size_t)b * 2 + 1) * C + c];
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
+    if ((lane & 63) == 0) { ws_[lane >> 6][0] = s; ws_[lane >> 6][1] = q; }
+    __syncthreads();
     if (lane == 0) {
+        s = 0.0; q = 0.0;
+#pragma unroll
+        for (int w = 0; w < FIN_T / 64; w++) { s += ws_[w][0]; q += ws_[w][1]; }
         coef[c] = (float)(s / (double)M);
         coef[C + c] = (float)(q / (double)M);
         coef[2 * C + c] = stat[2 * C + c];
@@ -303,7 +317,7 @@ int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const fl
         if (v8) bn_stats_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)y, ycs, C, M, ws);
         else bn_stats_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)y, ycs, C, M, ws);
         MI3D_LAUNCH_CHECK();
-        bn_stats_finalize_kernel<<<C, 64, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt,
+        bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt,
                                                  momentum, eps, stat);
         MI3D_LAUNCH_CHECK();
     });
@@ -313,7 +327,7 @@ int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const fl
 int bn_train_finalize(const float* part, int nblk, int C, int64_t M, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* stat,
                       hipStream_t s) {
-    bn_stats_finalize_kernel<<<C, 64, 0, s>>>(part, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
+    bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(part, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -352,7 +366,7 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
         if (v8) bn_bwd_reduce_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
         else bn_bwd_reduce_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
         MI3D_LAUNCH_CHECK();
-        bn_bwd_finalize_kernel<<<C, 64, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);
+        bn_bwd_finalize_kernel<<<C, FIN_T, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);
         MI3D_LAUNCH_CHECK();
         if (v8)
             bn_bwd_apply_kernel<T, 8><<<stream_grid(M * (C / 8), C / 8), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
@@ -374,7 +388,7 @@ int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, 
     size_t lds = (size_t)2 * R * C * sizeof(float);
     bn_stats_splitk_kernel<<<nblk, BLK, lds, s>>>(skp, ks, bias, (bf16*)y, ycs, C, M, ws);
     MI3D_LAUNCH_CHECK();
-    bn_stats_finalize_kernel<<<C, 64, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
+    bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
