@@ -635,11 +635,11 @@ inline int persist_grid(int Cin, int Cout, Geo g) {
 }
 
 // y[v][c] = bf16(bias[c] + sum_k part[k][v][c]); 8 channels per thread
-__global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int64_t M, int C,
-                                                            const float* __restrict__ bias, bf16* __restrict__ y, int ycs) {
+__device__ __forceinline__ void splitk_finish_body(int blk, int nblk, const float* __restrict__ part, int ksplit, int64_t M, int C,
+                                                   const float* __restrict__ bias, bf16* __restrict__ y, int ycs) {
     int G8 = C / 8;
     int64_t total = M * G8;
-    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+    for (int64_t idx = (int64_t)blk * BLK + threadIdx.x; idx < total; idx += (int64_t)nblk * BLK) {
         int64_t v = idx / G8;
         int c0 = (int)(idx - v * G8) * 8;
         float a[8];
@@ -652,6 +652,11 @@ __global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restr
         }
         st8<bf16>(y + v * ycs + c0, a);
     }
+}
+
+__global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int64_t M, int C,
+                                                            const float* __restrict__ bias, bf16* __restrict__ y, int ycs) {
+    splitk_finish_body((int)blockIdx.x, (int)gridDim.x, part, ksplit, M, C, bias, y, ycs);
 }
 
 template <int TZ, int TYB, int TXB, int BX, int COB>
@@ -1253,13 +1258,13 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
 // parallelism has to come from the slab dimension).  MFMA_LAYOUT: slab elements are in the (tap, co-block, ci-block,
 // lane, reg) order written above and are un-permuted to torch's (Cout, Cin, 27) here.
 template <bool MFMA_LAYOUT, int EW>
-__global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
-                                                           int64_t nW, float* __restrict__ dW, float* __restrict__ db,
-                                                           int accumulate, int Cin, int Cout) {
+__device__ __forceinline__ void slab_reduce2_body(int blk, const float* __restrict__ slabs, int nslab, int64_t slab_sz,
+                                                  int64_t nW, float* __restrict__ dW, float* __restrict__ db,
+                                                  int accumulate, int Cin, int Cout) {
     constexpr int SG = BLK / EW;
     __shared__ float red[SG][EW];
     int e = threadIdx.x % EW, sg = threadIdx.x / EW;
-    int64_t i = (int64_t)blockIdx.x * EW + e;
+    int64_t i = (int64_t)blk * EW + e;
     float s = 0.f;
     if (i < slab_sz)
         for (int b = sg; b < nslab; b += SG) s += slabs[(int64_t)b * slab_sz + i];
@@ -1285,15 +1290,22 @@ __global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restri
     }
 }
 
+template <bool MFMA_LAYOUT, int EW>
+__global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
+                                                           int64_t nW, float* __restrict__ dW, float* __restrict__ db,
+                                                           int accumulate, int Cin, int Cout) {
+    slab_reduce2_body<MFMA_LAYOUT, EW>((int)blockIdx.x, slabs, nslab, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+}
+
 // Large weight tensors (few slabs, MBs of output): one block per (co-block, ci-block, 4-row group G) sums the 27 tap
 // tiles' 64-float row groups (256 B contiguous reads), transposes through LDS and writes the four (co) rows'
 // contiguous 16 ci x 27 tap runs -- the scattered 4-byte stores of the kernel above cost 4x the time there.
-__global__ __launch_bounds__(BLK) void slab_reduce_tile_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
-                                                               int64_t nW, float* __restrict__ dW, float* __restrict__ db,
-                                                               int accumulate, int Cin, int Cout) {
+__device__ __forceinline__ void slab_reduce_tile_body(int blk, const float* __restrict__ slabs, int nslab, int64_t slab_sz,
+                                                      int64_t nW, float* __restrict__ dW, float* __restrict__ db,
+                                                      int accumulate, int Cin, int Cout) {
     __shared__ float out[4 * 16 * 27];
     int CIBN = Cin / 16, COBN = Cout / 16;
-    int t = blockIdx.x;
+    int t = blk;
     int G = t & 3; t >>= 2;
     int ib = t % CIBN, cb = t / CIBN;
     constexpr int NE = (27 * 64 + BLK - 1) / BLK;
@@ -1322,13 +1334,34 @@ __global__ __launch_bounds__(BLK) void slab_reduce_tile_kernel(const float* __re
         float v = out[m];
         dW[o] = accumulate ? dW[o] + v : v;
     }
-    if (db && blockIdx.x == 0) {
+    if (db && blk == 0) {
         for (int c = threadIdx.x; c < Cout; c += BLK) {
             float s = 0.f;
             for (int b = 0; b < nslab; b++) s += slabs[(int64_t)b * slab_sz + nW + c];
             db[c] = accumulate ? db[c] + s : s;
         }
     }
+}
+
+__global__ __launch_bounds__(BLK) void slab_reduce_tile_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
+                                                               int64_t nW, float* __restrict__ dW, float* __restrict__ db,
+                                                               int accumulate, int Cin, int Cout) {
+    slab_reduce_tile_body((int)blockIdx.x, slabs, nslab, slab_sz, nW, dW, db, accumulate, Cin, Cout);
+}
+
+// tail of a fused backward launch in ONE launch: blocks [0, nfin) finish the split-K input gradient, the rest sum the
+// weight-gradient slabs (every kernel node on the stream is a link of the step's dependent chain)
+struct TailArgs {
+    const float* part; int ks; int64_t M; int C; bf16* y; int ycs; int nfin;
+    const float* slabs; int nslab; int64_t slab_sz, nW; float* dW; float* db; int accumulate, Cin, Cout, layout, ew;
+};
+__global__ __launch_bounds__(BLK) void bwd_tail_kernel(TailArgs a) {
+    int b = blockIdx.x;
+    if (b < a.nfin) { splitk_finish_body(b, a.nfin, a.part, a.ks, a.M, a.C, nullptr, a.y, a.ycs); return; }
+    b -= a.nfin;
+    if (a.layout == 2) slab_reduce_tile_body(b, a.slabs, a.nslab, a.slab_sz, a.nW, a.dW, a.db, a.accumulate, a.Cin, a.Cout);
+    else if (a.ew == 8) slab_reduce2_body<true, 8>(b, a.slabs, a.nslab, a.slab_sz, a.nW, a.dW, a.db, a.accumulate, a.Cin, a.Cout);
+    else slab_reduce2_body<true, 32>(b, a.slabs, a.nslab, a.slab_sz, a.nW, a.dW, a.db, a.accumulate, a.Cin, a.Cout);
 }
 
 struct WgCfg { int cob, cib, nt, tg, nsb; };
@@ -1502,6 +1535,20 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     else if (ks > 1) conv3_bwd_fused_kernel<false, true><<<nblk, BLK, lds, s>>>(a);
     else conv3_bwd_fused_kernel<false, false><<<nblk, BLK, lds, s>>>(a);
     MI3D_LAUNCH_CHECK();
+    if (ks > 1 && !getenv("MI3D_NO_BWD_TAIL")) {
+        int64_t tot = g.M() * (Cin / 8);
+        TailArgs t;
+        t.part = skws; t.ks = ks; t.M = g.M(); t.C = Cin; t.y = (bf16*)dx; t.ycs = dxcs;
+        t.nfin = (int)(cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK));
+        t.slabs = wgws; t.nslab = c.nsb; t.slab_sz = slab_sz; t.nW = nW; t.dW = dW; t.db = db; t.accumulate = accumulate;
+        t.Cin = Cin; t.Cout = Cout;
+        t.layout = (dW && slab_sz >= (800 << 10)) ? 2 : 1;
+        t.ew = slab_sz < (16 << 10) ? 8 : 32;
+        int nsl = t.layout == 2 ? (Cout / 16) * (Cin / 16) * 4 : (int)cdiv(slab_sz, (int64_t)t.ew);
+        bwd_tail_kernel<<<t.nfin + nsl, BLK, 0, s>>>(t);
+        MI3D_LAUNCH_CHECK();
+        return 0;
+    }
     if (ks > 1) {
         int64_t tot = g.M() * (Cin / 8);
         splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ks, g.M(), Cin, nullptr, (bf16*)dx, dxcs);
