@@ -179,11 +179,12 @@ __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
+// nred = blocks of the reduction proper (= gridDim.x unless a slab-sum job rides behind them, see bn_bwd)
 template <typename T, int VEC>
-__global__ __launch_bounds__(BLK) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
-                                                            int ycs, int C, int64_t M, int64_t V,
-                                                            const float* __restrict__ stat,
-                                                            const float* __restrict__ drop, float* __restrict__ part) {
+__device__ __forceinline__ void bn_bwd_reduce_body(int nred, const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
+                                                   int ycs, int C, int64_t M, int64_t V,
+                                                   const float* __restrict__ stat,
+                                                   const float* __restrict__ drop, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int r, g, R;
     bool active = row_map<VEC>(C, r, g, R);
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(BLK) void bn_bwd_reduce_kernel(const T* __restrict_
             mean[i] = stat[g * VEC + i]; inv[i] = stat[C + g * VEC + i];
             a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i];
         }
-        for (int64_t row = (int64_t)blockIdx.x * R + r; row < M; row += (int64_t)gridDim.x * R) {
+        for (int64_t row = (int64_t)blockIdx.x * R + r; row < M; row += (int64_t)nred * R) {
             float yv[VEC], gv[VEC];
             ldv<T, VEC>(y + row * ycs + g * VEC, yv);
             ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
@@ -213,6 +214,23 @@ __global__ __launch_bounds__(BLK) void bn_bwd_reduce_kernel(const T* __restrict_
         }
     }
     block_colreduce<VEC, 2>(acc, C, active, lds, part);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
+                                                            int ycs, int C, int64_t M, int64_t V,
+                                                            const float* __restrict__ stat,
+                                                            const float* __restrict__ drop, float* __restrict__ part) {
+    bn_bwd_reduce_body<T, VEC>((int)gridDim.x, dz, dzcs, y, ycs, C, M, V, stat, drop, part);
+}
+// the same with a pending weight-gradient slab sum in the blocks behind the reduction's: one chain link less
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLK) void bn_bwd_reduce_slab_kernel(int nred, const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
+                                                                 int ycs, int C, int64_t M, int64_t V,
+                                                                 const float* __restrict__ stat,
+                                                                 const float* __restrict__ drop, float* __restrict__ part, SlabJob job) {
+    if ((int)blockIdx.x < nred) bn_bwd_reduce_body<T, VEC>(nred, dz, dzcs, y, ycs, C, M, V, stat, drop, part);
+    else slab_job_run(job, (int)blockIdx.x - nred);
 }
 
 // coef[3][C] = {c1 = sum_dyh / M, c2 = sum_dyh_xhat / M, g = gamma*invstd(=a)}; dgamma, dbeta (+)=
@@ -354,7 +372,7 @@ int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int6
 
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta, int accumulate,
-           float* ws, hipStream_t s) {
+           float* ws, hipStream_t s, const SlabJob* extra) {
     MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_bwd: bad C=%d", C);
     float* part = ws;
     float* coef = ws + (size_t)MAXBLK * 2 * C;
@@ -363,7 +381,11 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
         int G = v8 ? C / 8 : C, R = BLK / G;
         int nblk = reduce_grid(M, R);
         size_t lds = (size_t)2 * R * C * sizeof(float);
-        if (v8) bn_bwd_reduce_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
+        if (extra && extra->nblocks > 0) {
+            int tot = nblk + extra->nblocks;
+            if (v8) bn_bwd_reduce_slab_kernel<T, 8><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra);
+            else bn_bwd_reduce_slab_kernel<T, 1><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra);
+        } else if (v8) bn_bwd_reduce_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
         else bn_bwd_reduce_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
         MI3D_LAUNCH_CHECK();
         bn_bwd_finalize_kernel<<<C, FIN_T, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);

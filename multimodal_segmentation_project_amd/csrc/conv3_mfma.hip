@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "ops.h"
+#include "slab_sum.h"
 
 namespace {
 
@@ -1258,89 +1259,10 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
 // parallelism has to come from the slab dimension).  MFMA_LAYOUT: slab elements are in the (tap, co-block, ci-block,
 // lane, reg) order written above and are un-permuted to torch's (Cout, Cin, 27) here.
 template <bool MFMA_LAYOUT, int EW>
-__device__ __forceinline__ void slab_reduce2_body(int blk, const float* __restrict__ slabs, int nslab, int64_t slab_sz,
-                                                  int64_t nW, float* __restrict__ dW, float* __restrict__ db,
-                                                  int accumulate, int Cin, int Cout) {
-    constexpr int SG = BLK / EW;
-    __shared__ float red[SG][EW];
-    int e = threadIdx.x % EW, sg = threadIdx.x / EW;
-    int64_t i = (int64_t)blk * EW + e;
-    float s = 0.f;
-    if (i < slab_sz)
-        for (int b = sg; b < nslab; b += SG) s += slabs[(int64_t)b * slab_sz + i];
-    red[sg][e] = s;
-    __syncthreads();
-    if (sg == 0 && i < slab_sz) {
-        float tsum = 0.f;
-#pragma unroll
-        for (int k = 0; k < SG; k += 8)
-            tsum += ((red[k][e] + red[k + 1][e]) + (red[k + 2][e] + red[k + 3][e])) +
-                    ((red[k + 4][e] + red[k + 5][e]) + (red[k + 6][e] + red[k + 7][e]));
-        if (i < nW) {
-            int64_t o = i;
-            if (MFMA_LAYOUT) {
-                int r = i & 3, lane = (i >> 2) & 63; int64_t t = i >> 8;
-                int CIBN = Cin / 16, COBN = Cout / 16;
-                int cib = t % CIBN; t /= CIBN; int cob = t % COBN; int tap = t / COBN;
-                int co = cob * 16 + 4 * (lane >> 4) + r, ci = cib * 16 + (lane & 15);
-                o = ((int64_t)co * Cin + ci) * 27 + tap;
-            }
-            if (dW) dW[o] = accumulate ? dW[o] + tsum : tsum;
-        } else if (db) { db[i - nW] = accumulate ? db[i - nW] + tsum : tsum; }
-    }
-}
-
-template <bool MFMA_LAYOUT, int EW>
 __global__ __launch_bounds__(BLK) void slab_reduce2_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
                                                            int64_t nW, float* __restrict__ dW, float* __restrict__ db,
                                                            int accumulate, int Cin, int Cout) {
     slab_reduce2_body<MFMA_LAYOUT, EW>((int)blockIdx.x, slabs, nslab, slab_sz, nW, dW, db, accumulate, Cin, Cout);
-}
-
-// Large weight tensors (few slabs, MBs of output): one block per (co-block, ci-block, 4-row group G) sums the 27 tap
-// tiles' 64-float row groups (256 B contiguous reads), transposes through LDS and writes the four (co) rows'
-// contiguous 16 ci x 27 tap runs -- the scattered 4-byte stores of the kernel above cost 4x the time there.
-__device__ __forceinline__ void slab_reduce_tile_body(int blk, const float* __restrict__ slabs, int nslab, int64_t slab_sz,
-                                                      int64_t nW, float* __restrict__ dW, float* __restrict__ db,
-                                                      int accumulate, int Cin, int Cout) {
-    __shared__ float out[4 * 16 * 27];
-    int CIBN = Cin / 16, COBN = Cout / 16;
-    int t = blk;
-    int G = t & 3; t >>= 2;
-    int ib = t % CIBN, cb = t / CIBN;
-    constexpr int NE = (27 * 64 + BLK - 1) / BLK;
-    float acc[NE];
-    const float* p[NE];
-#pragma unroll
-    for (int k = 0; k < NE; k++) {
-        int e = threadIdx.x + k * BLK;
-        int tap = e < 27 * 64 ? (e >> 6) : 26, j = e & 63;
-        p[k] = slabs + (((int64_t)tap * COBN + cb) * CIBN + ib) * 256 + G * 64 + j;
-        acc[k] = 0.f;
-    }
-    for (int b = 0; b < nslab; b++) {              // NE independent 256 B-coalesced loads in flight per slab
-#pragma unroll
-        for (int k = 0; k < NE; k++) acc[k] += p[k][(int64_t)b * slab_sz];
-    }
-#pragma unroll
-    for (int k = 0; k < NE; k++) {
-        int e = threadIdx.x + k * BLK;
-        if (e < 27 * 64) { int tap = e >> 6, j = e & 63; out[((j & 3) * 16 + (j >> 2)) * 27 + tap] = acc[k]; }
-    }
-    __syncthreads();
-    for (int m = threadIdx.x; m < 4 * 432; m += BLK) {
-        int r = m / 432, k = m - r * 432;
-        int64_t o = ((int64_t)(cb * 16 + 4 * G + r) * Cin + ib * 16) * 27 + k;
-        float v = out[m];
-        dW[o] = accumulate ? dW[o] + v : v;
-    }
-    if (db && blk == 0) {
-        for (int c = threadIdx.x; c < Cout; c += BLK) {
-            float s = 0.f;
-            for (int b = 0; b < nslab; b++) s += slabs[(int64_t)b * slab_sz + nW + c];
-            db[c] = accumulate ? db[c] + s : s;
-        }
-    }
 }
 
 __global__ __launch_bounds__(BLK) void slab_reduce_tile_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_sz,
@@ -1411,8 +1333,18 @@ inline int c1_nsb(Geo g) {
 
 }  // namespace
 
-static int wgrad_slab_sum(float* ws, int nsb, int Cin, int Cout, float* dW, float* db, int accumulate, hipStream_t s) {
+__global__ __launch_bounds__(BLK) void slab_job_kernel(SlabJob q) { slab_job_run(q, (int)blockIdx.x); }
+int slab_job_launch(const SlabJob& q, hipStream_t s) {
+    if (q.nblocks <= 0) return 0;
+    slab_job_kernel<<<q.nblocks, BLK, 0, s>>>(q);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+static int wgrad_slab_sum(float* ws, int nsb, int Cin, int Cout, float* dW, float* db, int accumulate, hipStream_t s,
+                          SlabJob* pend = nullptr) {
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
+    if (pend) { *pend = slab_job_make((dW && slab_sz >= (800 << 10)) ? 2 : 1, ws, nsb, slab_sz, nW, dW, db, Cin, Cout, accumulate); return 0; }
     if (dW && slab_sz >= (800 << 10))
         slab_reduce_tile_kernel<<<(Cout / 16) * (Cin / 16) * 4, BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, Cin, Cout);
     else if (slab_sz < (16 << 10))
@@ -1429,7 +1361,7 @@ size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g) {
 }
 
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
-                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh) {
+                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh, SlabJob* pend) {
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0, "conv3_mfma_wgrad: unsupported channels");
     WgCfg c = wgrad_cfg(Cin, Cout, g);
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
@@ -1439,7 +1371,7 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     if (c.cob == 1 && c.cib == 1) rc = launch_wgrad<1, 1, 27>(xp, xcs, Cin, dp, dycs, Cout, g, ws, c, s, xh);
     else { MI3D_CHECK_ARG(false, "conv3_mfma_wgrad: no kernel for this block config"); return -1; }
     MI3D_TRY(rc);
-    return wgrad_slab_sum(ws, c.nsb, Cin, Cout, dW, db, accumulate, s);
+    return wgrad_slab_sum(ws, c.nsb, Cin, Cout, dW, db, accumulate, s, pend);
 }
 
 // full-resolution layers: dgrad on the persistent body (Cout -> Cin must be one of its shapes)
@@ -1449,7 +1381,7 @@ bool conv3_mfma_bwd_fused_persist_ok(int Cin, int Cout, int xcs, int dycs, Geo g
 }
 int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                                  int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats,
-                                 hipStream_t s, Halves xh, Halves dxh) {
+                                 hipStream_t s, Halves xh, Halves dxh, SlabJob* pend) {
     MI3D_CHECK_ARG(conv3_mfma_bwd_fused_persist_ok(Cin, Cout, xcs, dycs, g) && dx, "conv3_mfma_bwd_fused_persist: unsupported layer");
     int groups = (Cout / 16) * (Cin / 16);
     int64_t ntw = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
@@ -1489,7 +1421,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     else FP(2, 1);
 #undef FP
     MI3D_LAUNCH_CHECK();
-    return wgrad_slab_sum(wgws, nsb, Cin, Cout, dW, db, accumulate, s);
+    return wgrad_slab_sum(wgws, nsb, Cin, Cout, dW, db, accumulate, s, pend);
 }
 
 bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g) {
@@ -1502,7 +1434,7 @@ bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo
 
 int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                          int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats, float* skws,
-                         hipStream_t s) {
+                         hipStream_t s, SlabJob* pend) {
     MI3D_CHECK_ARG(conv3_mfma_bwd_fused_ok(Cin, Cout, xcs, dycs, dxcs, g) && dx && ((uintptr_t)dx % 16) == 0 && skws,
                    "conv3_mfma_bwd_fused: unsupported layer %d->%d", Cin, Cout);
     WgCfg c = wgrad_cfg(Cin, Cout, g);
@@ -1554,12 +1486,12 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
         splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ks, g.M(), Cin, nullptr, (bf16*)dx, dxcs);
         MI3D_LAUNCH_CHECK();
     }
-    return wgrad_slab_sum(wgws, c.nsb, Cin, Cout, dW, db, accumulate, s);
+    return wgrad_slab_sum(wgws, c.nsb, Cin, Cout, dW, db, accumulate, s, pend);
 }
 
 // first layer: x fp32 single channel (N,D,H,W), dy bf16 channels-last, Cout % 16 == 0
 int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db, int accumulate,
-                        float* ws, size_t ws_floats, hipStream_t s) {
+                        float* ws, size_t ws_floats, hipStream_t s, SlabJob* pend) {
     MI3D_CHECK_ARG(Cout % 16 == 0 && dycs % 8 == 0, "conv3_mfma_wgrad_c1: unsupported channels");
     int nsb = c1_nsb(g);
     int64_t nW = (int64_t)Cout * 27, slab_sz = nW + Cout;
@@ -1568,6 +1500,7 @@ int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo 
     conv3_wgrad_c1_kernel<<<grid, BLK, 0, s>>>(x, (const bf16*)dy, dycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ), cdiv(g.H, WTY),
                                                cdiv(g.W, WTX), ws);
     MI3D_LAUNCH_CHECK();
+    if (pend) { *pend = slab_job_make(0, ws, nsb, slab_sz, nW, dW, db, 1, Cout, accumulate); return 0; }
     slab_reduce2_kernel<false, 8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate, 1, Cout);
     MI3D_LAUNCH_CHECK();
     return 0;

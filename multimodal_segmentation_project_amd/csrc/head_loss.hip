@@ -687,7 +687,7 @@ int conv1_fwd(int dtype, const void* z, int zcs, int Cin, const float* w, const 
 size_t conv1_bwd_ws_floats(int Cin, int Cout) { return (size_t)8192 * ((size_t)Cin * Cout + Cout); }
 
 int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const float* dlogits, int Cout, void* dz,
-              int dzcs, float* dW, float* db, int accumulate, float* ws, int N, int64_t V, hipStream_t s) {
+              int dzcs, float* dW, float* db, int accumulate, float* ws, int N, int64_t V, hipStream_t s, SlabJob* pend) {
     MI3D_CHECK_ARG(Cout <= MAXC, "conv1_bwd: out_channels %d > %d unsupported", Cout, MAXC);
     MI3D_CHECK_ARG(N <= CONV1_NBLK, "conv1_bwd: batch %d > %d unsupported", N, CONV1_NBLK);
     int64_t nW = (int64_t)Cin * Cout;
@@ -702,6 +702,7 @@ int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const 
         dim3 grid((unsigned)bx, (unsigned)N, (unsigned)(Cin / 16));
         conv1_bwd_mfma_kernel<<<grid, C1W * 64, 0, s>>>((const bf16*)z, zcs, Cin, w, dlogits, Cout, (bf16*)dz, dzcs, V, ws);
         MI3D_LAUNCH_CHECK();
+        if (pend) { *pend = slab_job_make(0, ws, bx * N, nW + Cout, nW, dW, db, Cin, Cout, accumulate); return 0; }
         return slab_reduce(ws, bx * N, nW + Cout, nW, dW, db, accumulate, s);
     }
     DISPATCH_T(dtype, T, {

@@ -5,6 +5,7 @@
 // The extern "C" boundary (include/mi3d.h, api.hip) and the whole-network plan (plan.hip) sit on top.
 #pragma once
 #include "common.h"
+#include "slab_sum.h"
 
 struct Geo {
     int N, D, H, W;
@@ -54,23 +55,25 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
 
 size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
-                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh = Halves());
+                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh = Halves(), SlabJob* pend = nullptr);
+// pend != NULL (here and below): the final slab sum is NOT launched; its job is returned for the caller to attach to
+// the next kernel on the chain (bn_bwd) or to run with slab_job_launch
 
 // deep levels: weight gradient and input-gradient conv of one layer in ONE launch (independent, latency-bound each)
 bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g);
 int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                          int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats, float* skws,
-                         hipStream_t s);
+                         hipStream_t s, SlabJob* pend = nullptr);
 bool conv3_mfma_bwd_fused_persist_ok(int Cin, int Cout, int xcs, int dycs, Geo g);
 int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                                  int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats,
-                                 hipStream_t s, Halves xh = Halves(), Halves dxh = Halves());
+                                 hipStream_t s, Halves xh = Halves(), Halves dxh = Halves(), SlabJob* pend = nullptr);
 // first layer (Cin = 1, fp32 input) forward on the matrix cores (K = taps); optional BN partial sums like conv3_mfma_fwd
 int conv3_c1_fwd_stat_blocks(Geo g);
 int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,
                       hipStream_t s);
 int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db, int accumulate,
-                        float* ws, size_t ws_floats, hipStream_t s);
+                        float* ws, size_t ws_floats, hipStream_t s, SlabJob* pend = nullptr);
 
 // ---- BatchNorm3d + ReLU + Dropout3d ---------------------------------------------------------- bn.hip
 // Reference: nn.BatchNorm3d / nn.ReLU(inplace) / nn.Dropout3d  models/unet.py:12-14,16-18.
@@ -91,7 +94,9 @@ int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int6
 // dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)), dyh = dz*drop*[a*y+b > 0]; dgamma, dbeta (+)=
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
-           int accumulate, float* ws, hipStream_t s);
+           int accumulate, float* ws, hipStream_t s, const SlabJob* extra = nullptr);
+// extra: a pending slab sum that rides in the reduction kernel's launch (extra blocks)
+int slab_job_launch(const SlabJob& q, hipStream_t s);
 
 // split-K conv finish (y = bf16(bias + sum_k skp[k][M][C])) fused with the batch statistics of the stored values
 int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, int ycs, int C, int64_t M, const float* gamma,
@@ -124,7 +129,7 @@ int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const floa
                      Geo g, hipStream_t s);
 size_t upconv2_mfma_bwd_ws_floats(int Cin, int Cout, Geo g);
 int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, int Cout, const void* wp, void* dx,
-                     int dxcs, float* dW, float* db, int accumulate, float* ws, size_t ws_floats, Geo g, hipStream_t s);
+                     int dxcs, float* dW, float* db, int accumulate, float* ws, size_t ws_floats, Geo g, hipStream_t s, SlabJob* pend = nullptr);
 
 // ---- final 1x1x1 conv, losses, metrics ------------------------------------------------ head_loss.hip
 // Reference: nn.Conv3d(16,4,1) models/unet.py:62,87 ; utils/metrics.py:14-40,65-129,137-190.
@@ -133,7 +138,7 @@ int conv1_fwd(int dtype, const void* z, int zcs, int Cin, const float* w, const 
 size_t conv1_bwd_ws_floats(int Cin, int Cout);
 int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const float* dlogits, int Cout,
               void* dz, int dzcs, float* dW, float* db, int accumulate, float* ws, int N, int64_t V,
-              hipStream_t s);
+              hipStream_t s, SlabJob* pend = nullptr);
 
 struct LossCfg {
     float w_ce;       // weight of mean cross-entropy

@@ -185,6 +185,21 @@ struct Ctx {
     mutable int seq = 0;
     mutable bool rec[2] = {false, false};       // done-events recorded by this call (aux-stream wgrads in flight)
     mutable bool packed = false;      // weight packs already done by the one-launch pack_all
+    // one pending weight-gradient slab sum: it rides in the next BatchNorm-backward reduction launch (or is flushed
+    // with its own launch when another one arrives first / at the end of the call)
+    mutable SlabJob pend;
+    mutable bool has_pend = false;
+    bool defer_slabs = false;
+    // called before ANY launch that writes the (single) slab workspace: an older pending sum must read it first.
+    // Returns where the launcher may leave its own slab sum instead of launching it (NULL: launch immediately)
+    SlabJob* pend_slot() const {
+        if (has_pend) { slab_job_launch(pend, s); has_pend = false; }
+        if (!defer_slabs) return nullptr;
+        pend = SlabJob();
+        return &pend;
+    }
+    void pend_filled() const { has_pend = defer_slabs && pend.nblocks > 0; }
+    int flush_pend() const { int rc = 0; if (has_pend) { rc = slab_job_launch(pend, s); has_pend = false; } return rc; }
     template <typename T = void> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
     const float* P(int i) const { return reinterpret_cast<const float*>(params[i]); }
 };
@@ -284,26 +299,32 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         int dcs = h == 1 ? dzcs : H.Cout;
         MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
                         drop ? drop + H.drop_off : nullptr, dyb, H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
-                        c.at<float>(p.bnws), c.s));
+                        c.at<float>(p.bnws), c.s, c.has_pend ? &c.pend : nullptr));
+        c.has_pend = false;
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
         void* dx_f = h == 1 ? c.at(p.sC) : dxin;
         int dxs_f = h == 1 ? H.Cin : dxcs;
         if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && conv3_mfma_bwd_fused_persist_ok(H.Cin, H.Cout, ics, H.Cout, g)) {
             Halves hv = (h == 0 && b > p.L) ? p.halves(B.level) : Halves();
+            SlabJob* ps = c.pend_slot();
             MI3D_TRY(conv3_mfma_bwd_fused_persist(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx),
-                                                  G(H.pidx + 1), accumulate, c.at<float>(p.wgws), p.wgws_floats, c.s, hv, hv));
+                                                  G(H.pidx + 1), accumulate, c.at<float>(p.wgws), p.wgws_floats, c.s, hv, hv, ps));
+            c.pend_filled();
             continue;
         }
         if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && !(h == 0 && b > p.L && p.planar[B.level]) &&
             conv3_mfma_bwd_fused_ok(H.Cin, H.Cout, ics, H.Cout, dxs_f, g)) {
+            SlabJob* ps = c.pend_slot();
             MI3D_TRY(conv3_mfma_bwd_fused(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx), G(H.pidx + 1),
-                                          accumulate, c.at<float>(p.wgws), p.wgws_floats, c.at<float>(p.skws), c.s));
+                                          accumulate, c.at<float>(p.wgws), p.wgws_floats, c.at<float>(p.skws), c.s, ps));
+            c.pend_filled();
             continue;
         }
         if (G(H.pidx) || G(H.pidx + 1)) {
             hipStream_t ws_ = c.s;
             float* wgws = c.at<float>(p.wgws);
+            SlabJob* ps = two ? nullptr : c.pend_slot();
             if (two) {
                 MI3D_HIP(hipEventRecord(c.ev[k & 1], c.s));
                 MI3D_HIP(hipStreamWaitEvent(c.s2, c.ev[k & 1], 0));
@@ -312,13 +333,14 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             }
             if (H.mfma)
                 MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
-                                          wgws, p.wgws_floats, ws_, (h == 0 && b > p.L) ? p.halves(B.level) : Halves()));
+                                          wgws, p.wgws_floats, ws_, (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), ps));
             else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT"))
                 MI3D_TRY(conv3_mfma_wgrad_c1((const float*)in, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
-                                             wgws, p.wgws_floats, ws_));
+                                             wgws, p.wgws_floats, ws_, ps));
             else
                 MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
                                             accumulate, wgws, p.wgws_floats, ws_));
+            if (!two) c.pend_filled();
             if (two) { MI3D_HIP(hipEventRecord(c.ev[2 + (k & 1)], c.s2)); c.rec[k & 1] = true; }
         }
         void* dx = h == 1 ? c.at(p.sC) : dxin;
@@ -443,13 +465,16 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
     Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
     if (aux_stream && events) { c.s2 = (hipStream_t)aux_stream; c.ev = (hipEvent_t*)events; }
     float* wgws = c.at<float>(p.wgws);
+    c.defer_slabs = !getenv("MI3D_NO_PEND_SLABS");
     auto G = [&](int i) { return (float*)grads[i]; };
     for (int seg = seg_begin; seg < seg_end; seg++) {
         if (seg == 0) {
             if (!dlogits) continue;
+            SlabJob* ps = c.pend_slot();
             MI3D_TRY(conv1_bwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), dlogits, d->out_channels,
                                c.at(p.gz[0]), p.C[0], G(p.final_pidx()), G(p.final_pidx() + 1), accumulate, wgws, d->N,
-                               p.geo[0].V(), c.s));
+                               p.geo[0].V(), c.s, ps));
+            c.pend_filled();
         } else if (seg <= L) {
             if (!dlogits) continue;
             int l = seg - 1, i = L - 1 - l;       // decoder.i works at level l
@@ -458,11 +483,13 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
             float* wf = c.at<float>(p.upw[i]);
             float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
             char* gcatl = c.at<char>(p.gcat[l]);
-            if (p.up_mfma[i])
+            SlabJob* ps = c.pend_slot();
+            if (p.up_mfma[i]) {
                 MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gcatl + p.half_off(l), p.catcs(l), p.C[l],
                                           c.at(p.upw[i]), c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1),
-                                          accumulate, wgws, p.wgws_floats, p.geo[l + 1], c.s));
-            else
+                                          accumulate, wgws, p.wgws_floats, p.geo[l + 1], c.s, ps));
+                c.pend_filled();
+            } else
                 MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gcatl + p.half_off(l), p.catcs(l), p.C[l], wb,
                                      c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1), accumulate, wgws,
                                      p.wgws_floats, p.geo[l + 1], c.s));
@@ -478,6 +505,7 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
             MI3D_TRY(block_backward(c, l, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], dx, l > 0 ? p.C[l - 1] : 0, accumulate));
         }
     }
+    MI3D_TRY(c.flush_pend());
     // join: everything the aux stream produced is ordered before whatever the caller enqueues next on `stream`
     for (int i = 0; i < 2; i++)
         if (c.rec[i]) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + i], 0));

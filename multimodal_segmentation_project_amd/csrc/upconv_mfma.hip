@@ -421,7 +421,7 @@ size_t upconv2_mfma_bwd_ws_floats(int Cin, int Cout, Geo g) {
 }
 
 int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, int Cout, const void* wp, void* dx, int dxcs,
-                     float* dW, float* db, int accumulate, float* ws, size_t ws_floats, Geo g, hipStream_t s) {
+                     float* dW, float* db, int accumulate, float* ws, size_t ws_floats, Geo g, hipStream_t s, SlabJob* pend) {
     MI3D_CHECK_ARG(upconv2_mfma_supported(Cin, Cout, xcs, gycs), "upconv2_mfma_bwd: unsupported channels");
     MI3D_CHECK_ARG(g.M() < (1ll << 31), "upconv2_mfma_bwd: more than 2^31 input voxels");
     const bf16* xp = (const bf16*)x; const bf16* gp = (const bf16*)gy;
@@ -462,6 +462,7 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         }
 #undef UFL
         MI3D_LAUNCH_CHECK();
+        if (pend) { *pend = slab_job_make(0, ws, nsb, slab_sz, nW, dW, db, Cin, Cout, accumulate); return 0; }
         if (slab_sz < (16 << 10)) slab_reduce3_kernel<8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
         else slab_reduce3_kernel<32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
         MI3D_LAUNCH_CHECK();
@@ -501,6 +502,7 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         dim3 grid((unsigned)nsb, (unsigned)(Cin / 32), (unsigned)cdiv(Cout, 32));
         upconv_mfma_bwd_weight_kernel<<<grid, BLK, lds, s>>>(xp, xcs, Cin, gp, gycs, Cout, g.N, g.D, g.H, g.W, ws);
         MI3D_LAUNCH_CHECK();
+        if (pend) { *pend = slab_job_make(0, ws, nsb, slab_sz, nW, dW, db, Cin, Cout, accumulate); return 0; }
         if (slab_sz < (16 << 10)) slab_reduce3_kernel<8><<<cdiv(slab_sz, 8), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
         else slab_reduce3_kernel<32><<<cdiv(slab_sz, 32), BLK, 0, s>>>(ws, nsb, slab_sz, nW, dW, db, accumulate);
         MI3D_LAUNCH_CHECK();
