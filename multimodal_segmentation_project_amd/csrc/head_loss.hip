@@ -442,8 +442,8 @@ __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restri
 
 // one 1024-thread block: wave w sums quantities w, w+16 over the block partials (lane-strided doubles + wave tree:
 // fixed order), then thread 0 computes the loss and the gradient coefficients
-__global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* __restrict__ part, int nblk, int N, int C,
-                                                                  int64_t V, LossCfg cfg, float* loss_out, float* coef) {
+__device__ __forceinline__ void seg_loss_finalize_body(const double* __restrict__ part, int nblk, int N, int C,
+                                                       int64_t V, LossCfg cfg, float* loss_out, float* coef) {
     __shared__ double sums[NQ];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int q = wave; q < NQ; q += 16) {
@@ -484,6 +484,11 @@ __global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* _
         coef[2 * MAXC + 3] = 0.f;
         *loss_out = (float)loss;
     }
+}
+
+__global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* __restrict__ part, int nblk, int N, int C,
+                                                                  int64_t V, LossCfg cfg, float* loss_out, float* coef) {
+    seg_loss_finalize_body(part, nblk, N, C, V, cfg, loss_out, coef);
 }
 
 template <int NC, int VV>
@@ -600,8 +605,8 @@ __global__ __launch_bounds__(BLK) void seg_metrics_kernel(const float* __restric
 }
 
 // Q1: the reference's class loop is range(1, pred.size(1)) AFTER argmax -> bound = first spatial dim D
-__global__ __launch_bounds__(1024) void seg_metrics_finalize_kernel(const unsigned long long* part, int nblk, int N, int C,
-                                                                    int D, int64_t V, float* out) {
+__device__ __forceinline__ void seg_metrics_finalize_body(const unsigned long long* part, int nblk, int N, int C,
+                                                          int D, int64_t V, float* out) {
     __shared__ unsigned long long counts[3 * MAXC + 1];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int q = wave; q < 3 * MAXC + 1; q += 16) {         // exact integer sums, wave-parallel
@@ -628,6 +633,19 @@ __global__ __launch_bounds__(1024) void seg_metrics_finalize_kernel(const unsign
     out[0] = iou / dv;
     out[1] = dice / dv;
     out[2] = (float)((double)counts[3 * MAXC] / ((double)N * (double)V));
+}
+
+__global__ __launch_bounds__(1024) void seg_metrics_finalize_kernel(const unsigned long long* part, int nblk, int N, int C,
+                                                                    int D, int64_t V, float* out) {
+    seg_metrics_finalize_body(part, nblk, N, C, D, V, out);
+}
+// both finalizes of the fused loss + metrics pass in one launch (one chain link less)
+__global__ __launch_bounds__(1024) void seg_loss_metrics_finalize_kernel(const double* __restrict__ part, const unsigned long long* cnt,
+                                                                         int nblk, int N, int C, int D, int64_t V, LossCfg cfg,
+                                                                         float* loss_out, float* coef, float* met_out) {
+    seg_loss_finalize_body(part, nblk, N, C, V, cfg, loss_out, coef);
+    __syncthreads();
+    seg_metrics_finalize_body(cnt, nblk, N, C, D, V, met_out);
 }
 
 // raw exact counts for the per-class evaluation metrics (test_model.py:242-285): out[0..C) n_inter, [C..2C) n_pred,
@@ -746,12 +764,9 @@ int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teache
     else SLF(MAXC, 1);
 #undef SLF
     MI3D_LAUNCH_CHECK();
-    seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, bx * N, N, C, V, cfg, loss_out, coef);
+    if (met) seg_loss_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, cw, bx * N, N, C, D, V, cfg, loss_out, coef, metrics_out);
+    else seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, bx * N, N, C, V, cfg, loss_out, coef);
     MI3D_LAUNCH_CHECK();
-    if (met) {
-        seg_metrics_finalize_kernel<<<1, 1024, 0, s>>>(cw, bx * N, N, C, D, V, metrics_out);
-        MI3D_LAUNCH_CHECK();
-    }
     return 0;
 }
 
