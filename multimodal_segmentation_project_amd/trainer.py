@@ -196,12 +196,19 @@ class TrainStep:
              ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
         nseg = st["nseg_run"]
         do_comm = self.world > 1 and boundary
+        aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
+        # one C call per run of segments between exchange steps: kernels of adjacent segments share launches (a
+        # weight-gradient slab sum rides in the next BatchNorm reduction), which a call boundary would cut
+        start = 0
         for seg in range(nseg):
-            call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop), ptr(st["dlogits"]),
-                 None, 1.0, accumulate, seg, seg + 1, ptr(st["ws"]), st["ws_bytes"], s,
-                 self.aux_stream.cuda_stream if self.aux_stream is not None else None, self._events)
-            if do_comm and seg in self.comm.buckets:
-                self._allreduce_bucket(seg)
+            last = seg == nseg - 1
+            if last or (do_comm and seg in self.comm.buckets):
+                call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
+                     ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
+                     self._events)
+                start = seg + 1
+                if do_comm and seg in self.comm.buckets:
+                    self._allreduce_bucket(seg)
         if do_comm:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         if boundary:
