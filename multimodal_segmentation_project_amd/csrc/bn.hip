@@ -168,7 +168,7 @@ __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, 
     for (; row < M; row += rstep) {
         float v[VEC], o[VEC];
         ldv<T, VEC>(y + row * ycs + g * VEC, v);
-        const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
+        const float* dr = drop ? drop + (int64_t)((unsigned)row / (unsigned)V) * C + g * VEC : nullptr;
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
             float t = fmaf(v[i], a[i], b[i]);
@@ -202,7 +202,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(int nred, const T* __restrict
             float yv[VEC], gv[VEC];
             ldv<T, VEC>(y + row * ycs + g * VEC, yv);
             ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
-            const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
+            const float* dr = drop ? drop + (int64_t)((unsigned)row / (unsigned)V) * C + g * VEC : nullptr;
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
                 float pre = fmaf(yv[i], a[i], b[i]);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(BLK) void bn_bwd_apply_kernel(const T* __restrict__
         float yv[VEC], gv[VEC], o[VEC];
         ldv<T, VEC>(y + row * ycs + g * VEC, yv);
         ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
-        const float* dr = drop ? drop + (row / V) * C + g * VEC : nullptr;
+        const float* dr = drop ? drop + (int64_t)((unsigned)row / (unsigned)V) * C + g * VEC : nullptr;
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
             float pre = fmaf(yv[i], a[i], b[i]);
@@ -360,6 +360,7 @@ int bn_eval_stats(int C, const float* gamma, const float* beta, const float* rm,
 int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* stat,
                        const float* drop, void* z, int zcs, hipStream_t s) {
     MI3D_CHECK_ARG(C >= 1 && M >= 1, "bn_apply: bad shape");
+    MI3D_CHECK_ARG(!drop || M < (1ll << 32), "bn_apply: dropout path needs M < 2^32 (32-bit sample index)");
     DISPATCH_T(dtype, T, {
         if (vec8_ok(C, ycs, zcs, y, z, sizeof(T)))
             bn_apply_kernel<T, 8><<<stream_grid(M * (C / 8), C / 8), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
@@ -374,6 +375,7 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta, int accumulate,
            float* ws, hipStream_t s, const SlabJob* extra) {
     MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_bwd: bad C=%d", C);
+    MI3D_CHECK_ARG(!drop || M < (1ll << 32), "bn_bwd: dropout path needs M < 2^32 (32-bit sample index)");
     float* part = ws;
     float* coef = ws + (size_t)MAXBLK * 2 * C;
     DISPATCH_T(dtype, T, {
