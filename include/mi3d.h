@@ -139,6 +139,9 @@ int mi3d_linear_forward(const float* x, const float* w, const float* b, float* y
 int mi3d_linear_backward(const float* x, const float* w, const float* y, const float* gy, int M, int K, int Nout,
                          int relu, const float* drop, float* gx, float* gw, float* gb, int accumulate,
                          float gx_scale, float* workspace, void* stream);
+/* y = alpha * (alpha_dev ? *alpha_dev : 1) * x over n floats.  GradientReversal.backward (train_dann.py:27-29:
+ * grad_output.neg() * lambda_) is alpha = -lambda; the row-CE backward multiplies by the upstream gradient alpha_dev. */
+int mi3d_scale(const float* x, float* y, int64_t n, float alpha, const float* alpha_dev, void* stream);
 /* mean CE over M rows; dlogits = scale * d(loss)/d(logits) (may be NULL) */
 int mi3d_softmax_ce_rows(const float* logits, const int64_t* labels, int M, int C, float* loss, float* dlogits,
                          float scale, void* stream);

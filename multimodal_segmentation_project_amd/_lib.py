@@ -52,6 +52,7 @@ _SIGS = {
     "mi3d_seg_class_counts": (i32, [vp, vp, i32, i32, i64, vp, vp, vp]),
     "mi3d_linear_forward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "mi3d_linear_backward": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp]),
+    "mi3d_scale": (i32, [vp, vp, i64, f32, vp, vp]),
     "mi3d_softmax_ce_rows": (i32, [vp, vp, i32, i32, vp, vp, f32, vp]),
     "mi3d_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp]),
     "mi3d_adamw_apply": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, i32, vp]),
@@ -106,7 +107,12 @@ def check(rc, what):
         raise Mi3dError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
 
 
+launches = 0      # bumped by every library call: lets caches notice device buffers rewritten behind torch's back
+
+
 def call(name, *args):
+    global launches
+    launches += 1
     check(getattr(lib(), name)(*args), name)
 
 

@@ -70,6 +70,11 @@ int mi3d_softmax_ce_rows(const float* logits, const int64_t* labels, int M, int 
     return softmax_ce_rows(logits, labels, M, C, loss, dlogits, scale, (hipStream_t)stream);
 }
 
+int mi3d_scale(const float* x, float* y, int64_t n, float alpha, const float* alpha_dev, void* stream) {
+    MI3D_CHECK_ARG(x && y && n >= 0, "mi3d_scale: bad arguments");
+    return scale_f32(x, y, n, alpha, alpha_dev, (hipStream_t)stream);
+}
+
 int mi3d_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float grad_scale, int64_t* step_dev, void* stream) {
     MI3D_CHECK_ARG(p && g && m && v && step_dev && n >= 0, "mi3d_adamw_step: bad arguments");
@@ -91,7 +96,9 @@ size_t mi3d_conv3_workspace_bytes(int Cin, int Cout, int N, int D, int H, int W)
     size_t wg = conv3_direct_wgrad_ws_floats(Cin, Cout, g);
     if ((conv3_mfma_supported(Cin, Cout, 16, 16) || (Cin == 1 && Cout % 16 == 0)) && conv3_mfma_wgrad_ws_floats(Cin, Cout, g) > wg)
         wg = conv3_mfma_wgrad_ws_floats(Cin, Cout, g);
-    return (conv3_direct_pack_floats(Cin, Cout) + conv3_direct_pack_floats(Cout, Cin) + wg) * sizeof(float);
+    // + the split-K scratch of the fused (input-gradient + weight-gradient) deep-level launch
+    size_t sk = conv3_mfma_supported(Cin, Cout, 16, 16) ? conv3_mfma_splitk_floats(Cout, Cin, g) : 0;
+    return (conv3_direct_pack_floats(Cin, Cout) + conv3_direct_pack_floats(Cout, Cin) + wg + sk + 64) * sizeof(float);
 }
 int mi3d_conv3_forward(int in_dtype, int out_dtype, const void* x, int xcs, int Cin, const float* w, const float* bias,
                        void* y, int ycs, int Cout, int N, int D, int H, int W, void* workspace, size_t workspace_bytes,
@@ -118,6 +125,22 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
     float* wpd = wpf + conv3_direct_pack_floats(Cin, Cout);
     float* slabs = wpd + conv3_direct_pack_floats(Cout, Cin);
     hipStream_t s = (hipStream_t)stream;
+    // the same kernel choice as the whole-network plan (plan.hip block_backward), so the per-operator parity tests pin
+    // the kernels the training step runs: both products of a layer in ONE fused launch where that exists
+    if (dx && (dW || db) && x_dtype == MI3D_BF16 && use_mfma(dy_dtype, dy_dtype, Cout, Cin, dycs, dxcs) &&
+        use_mfma(x_dtype, dy_dtype, Cin, Cout, xcs, dycs) && !getenv("MI3D_API_UNFUSED")) {
+        size_t wgf = conv3_mfma_wgrad_ws_floats(Cin, Cout, g);
+        if (conv3_direct_wgrad_ws_floats(Cin, Cout, g) > wgf) wgf = conv3_direct_wgrad_ws_floats(Cin, Cout, g);
+        float* skws = slabs + ((wgf + 63) & ~(size_t)63);
+        if (conv3_mfma_bwd_fused_persist_ok(Cin, Cout, xcs, dycs, g)) {
+            MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, g, s));
+            return conv3_mfma_bwd_fused_persist(x, xcs, Cin, dy, dycs, Cout, wpd, dx, dxcs, g, dW, db, accumulate, slabs, wgf, s);
+        }
+        if (conv3_mfma_bwd_fused_ok(Cin, Cout, xcs, dycs, dxcs, g)) {
+            MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, g, s));
+            return conv3_mfma_bwd_fused(x, xcs, Cin, dy, dycs, Cout, wpd, dx, dxcs, g, dW, db, accumulate, slabs, wgf, skws, s);
+        }
+    }
     if (dx && use_mfma(dy_dtype, dy_dtype, Cout, Cin, dycs, dxcs)) {
         MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, g, s));
         MI3D_TRY(conv3_mfma_fwd(dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, nullptr, nullptr, s));

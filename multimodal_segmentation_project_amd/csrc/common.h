@@ -117,3 +117,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
         if ((dtype) == MI3D_F32) { typedef float T; __VA_ARGS__ }  \
         else { typedef bf16 T; __VA_ARGS__ }                       \
     } while (0)
+
+// opt a kernel in to > 64 KB of dynamic LDS exactly once per process, safely from any host thread (the header promises
+// "callable from any host thread": PyTorch runs backward on its autograd thread).  KPTR: parenthesise template kernels.
+#ifdef __cplusplus
+#include <mutex>
+#define MI3D_SET_MAX_LDS_ONCE(KPTR, BYTES)                                                                   \
+    do {                                                                                                     \
+        static std::once_flag once_;                                                                         \
+        hipError_t e_once_ = hipSuccess;                                                                     \
+        std::call_once(once_, [&] {                                                                          \
+            e_once_ = hipFuncSetAttribute(reinterpret_cast<const void*>(KPTR),                               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));         \
+        });                                                                                                  \
+        MI3D_HIP(e_once_);                                                                                   \
+    } while (0)
+#endif

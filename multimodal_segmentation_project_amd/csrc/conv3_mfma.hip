@@ -1311,14 +1311,9 @@ inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
 template <int CO_B, int CI_B, int NT>
 int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int Cout, Geo g, float* slabs, WgCfg c,
                  hipStream_t s, Halves xh) {
-    static bool attr_set = false;
     size_t lds = (size_t)(CO_B * WNV + CI_B * WNH) * 32;
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
-    if (!attr_set) {
-        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_mfma_kernel<CO_B, CI_B, NT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    MI3D_SET_MAX_LDS_ONCE((&conv3_wgrad_mfma_kernel<CO_B, CI_B, NT>), lds);
     dim3 grid((unsigned)(c.nsb * c.tg), (unsigned)(Cout / (16 * CO_B)), (unsigned)(Cin / (16 * CI_B)));
     conv3_wgrad_mfma_kernel<CO_B, CI_B, NT><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W,
                                                                   cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh);
@@ -1408,12 +1403,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     do {                                                                                                                      \
         size_t ldsp = (size_t)(6 * 10 * 18 * 16 + NCH_ * 14 * COB_ * 512) * 2 + 4 * COB_ * 16 * 2 * 4;                        \
         size_t lds = ldsp > ldsw ? ldsp : ldsw;                                                                               \
-        static bool set_ = false;                                                                                             \
-        if (!set_) {                                                                                                          \
-            MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_persist_kernel<COB_, NCH_>),          \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
-            set_ = true;                                                                                                      \
-        }                                                                                                                     \
+        MI3D_SET_MAX_LDS_ONCE((&conv3_bwd_fused_persist_kernel<COB_, NCH_>), lds);                                            \
         conv3_bwd_fused_persist_kernel<COB_, NCH_><<<nblk, BLK, lds, s>>>(a);                                                   \
     } while (0)
     if (Cout == 16 && Cin == 16) FP(1, 1);
@@ -1452,16 +1442,9 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
     size_t lds = (size_t)(WNV + WNH) * 32;
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<false, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<false, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_fused_kernel<true, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    MI3D_SET_MAX_LDS_ONCE((&conv3_bwd_fused_kernel<false, true>), lds);
+    MI3D_SET_MAX_LDS_ONCE((&conv3_bwd_fused_kernel<false, false>), lds);
+    MI3D_SET_MAX_LDS_ONCE((&conv3_bwd_fused_kernel<true, false>), lds);
     unsigned nblk = (unsigned)(a.wgx * a.wgy * a.wgz + a.dgx * a.dgy * a.dgz);
     if (big) conv3_bwd_fused_kernel<true, false><<<nblk, BLK, lds, s>>>(a);
     else if (ks > 1) conv3_bwd_fused_kernel<false, true><<<nblk, BLK, lds, s>>>(a);

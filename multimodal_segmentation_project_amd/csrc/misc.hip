@@ -208,7 +208,18 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
 __global__ void scale_add_kernel(float* dst, const float* src, int64_t n, float a, float b) {
     for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) dst[i] = a * dst[i] + b * src[i];
 }
+// y = a * (*a_dev or 1) * x   (gradient reversal: a = -lambda; row-CE backward: a_dev = upstream gradient)
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float a, const float* __restrict__ a_dev) {
+    float f = a * (a_dev ? *a_dev : 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) y[i] = f * x[i];
+}
 }  // namespace
+
+int scale_f32(const float* x, float* y, int64_t n, float a, const float* a_dev, hipStream_t s) {
+    scale_kernel<<<sgrid(n), BLK, 0, s>>>(x, y, n, a, a_dev);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
 
 int slab_reduce(const float* slabs, int nslab, int64_t slab_sz, int64_t nW, float* dW, float* db, int accumulate,
                 hipStream_t s) {

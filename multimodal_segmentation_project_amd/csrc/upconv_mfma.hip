@@ -446,12 +446,7 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         unsigned nblk = (unsigned)(a.wgx * a.wgy * a.wgz + a.dgx * a.dgy);
 #define UFL(SS, KS_)                                                                                                          \
         do {                                                                                                                  \
-            static bool set_ = false;                                                                                         \
-            if (!set_) {                                                                                                      \
-                MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_mfma_bwd_fused_kernel<SS, KS_>),           \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-                set_ = true;                                                                                                  \
-            }                                                                                                                 \
+            MI3D_SET_MAX_LDS_ONCE((&upconv_mfma_bwd_fused_kernel<SS, KS_>), lds);                                             \
             upconv_mfma_bwd_fused_kernel<SS, KS_><<<nblk, BLK, lds, s>>>(a);                                                    \
         } while (0)
         switch (Cout / 4) {
@@ -492,13 +487,8 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         int nsb = upw_nsb(Cin, Cout, g);
         int64_t nW = (int64_t)Cin * Cout * 8, slab_sz = nW + Cout;
         MI3D_CHECK_ARG(ws_floats >= (size_t)nsb * slab_sz, "upconv2_mfma_bwd: workspace too small");
-        static bool attr_set = false;
         size_t lds = (size_t)(2 * UV + 16 * UV) * 32;
-        if (!attr_set) {
-            MI3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&upconv_mfma_bwd_weight_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        MI3D_SET_MAX_LDS_ONCE(&upconv_mfma_bwd_weight_kernel, lds);
         dim3 grid((unsigned)nsb, (unsigned)(Cin / 32), (unsigned)cdiv(Cout, 32));
         upconv_mfma_bwd_weight_kernel<<<grid, BLK, lds, s>>>(xp, xcs, Cin, gp, gycs, Cout, g.N, g.D, g.H, g.W, ws);
         MI3D_LAUNCH_CHECK();

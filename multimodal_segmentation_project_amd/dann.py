@@ -15,15 +15,21 @@ from ._lib import call, ptr, stream_ptr
 
 
 class GradientReversal(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, lambda_):
-        ctx.lambda_ = lambda_
-        return x.view_as(x)
+    """Identity forward; the gradient comes back multiplied by -lambda (one HIP launch).  The native DannStep does not
+    even launch that: it hands -lambda to the U-Net backward as its `gap_scale` argument."""
 
     @staticmethod
-    def backward(ctx, grad_output):
-        # (N, 256) elementwise scale: bookkeeping, not a hot kernel
-        return grad_output.neg() * ctx.lambda_, None
+    def forward(ctx, features, lambda_):
+        ctx.neg_scale = -float(lambda_)
+        return features.view_as(features)
+
+    @staticmethod
+    def backward(ctx, g):
+        _lib.require_cuda(g, "GradientReversal.backward")
+        g = g.contiguous().float()
+        out = torch.empty_like(g)
+        call("mi3d_scale", ptr(g), ptr(out), g.numel(), ctx.neg_scale, None, stream_ptr())
+        return out, None
 
 
 def grad_reverse(x, lambda_):
@@ -82,7 +88,11 @@ class DomainDiscriminator(nn.Module):
         _lib.require_cuda(x, "DomainDiscriminator.forward")
         lins = [self.net[0], self.net[3], self.net[6], self.net[8]]
         drops = [None, None, None, None]
-        if self.training:
+        injected = getattr(self, "_mi3d_injected_drop_scales", None)
+        if self.training and injected is not None:
+            for i in (0, 1):
+                drops[i] = injected[i].to(device=x.device, dtype=torch.float32).contiguous()
+        elif self.training:
             st = getattr(self, "_mi3d_rng_state", None)
             if st is None or st.device != x.device:
                 st = torch.tensor([(torch.initial_seed() + 0x5DEECE66D) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
@@ -114,7 +124,10 @@ class _RowCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        return d * g, None
+        g = g.contiguous().float()
+        out = torch.empty_like(d)
+        call("mi3d_scale", ptr(d), ptr(out), d.numel(), 1.0, ptr(g), stream_ptr())
+        return out, None
 
 
 def domain_ce(domain_preds, domain_labels):

@@ -61,26 +61,39 @@ def bucket_ranges(arena, n_levels):
 
 
 class DataParallelComm:
-    def __init__(self, arena, n_levels, group=None):
+    def __init__(self, arena, n_levels, group=None, force=False):
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # force: issue the collectives even in a 1-rank group (MI3D_FORCE_COMM: the RCCL path on a 1-GPU box)
+        self.enabled = self.world > 1 or (bool(force) and dist.is_available() and dist.is_initialized())
         self.buckets = bucket_ranges(arena, n_levels)
-        self.backend = dist.get_backend(group) if self.world > 1 else None
+        self.backend = dist.get_backend(group) if self.enabled else None
 
     def broadcast_parameters(self, buffers=()):
         """C1: rank 0's parameters (one flat broadcast) and buffers win."""
-        if self.world > 1:
+        if self.enabled:
             dist.broadcast(self.arena.p, src=0, group=self.group)
             self.sync_buffers(buffers)
 
     def sync_buffers(self, buffers):
-        """C3 replacement: rank 0's BN running statistics are authoritative; call before eval / checkpoint."""
-        if self.world > 1:
+        """C3 replacement: rank 0's BN running statistics are authoritative; call before eval / checkpoint.  ONE
+        coalesced broadcast (like DDP's): all buffers (fp32 statistics and int64 counters) travel as one byte string."""
+        if not self.enabled:
+            return
+        buffers = [b for b in buffers]
+        if not buffers:
+            return
+        flat = torch.cat([b.detach().reshape(-1).view(torch.uint8) for b in buffers])
+        dist.broadcast(flat, src=0, group=self.group)
+        off = 0
+        with torch.no_grad():
             for b in buffers:
-                dist.broadcast(b, src=0, group=self.group)
+                nb = b.numel() * b.element_size()
+                b.copy_(flat[off:off + nb].view(b.dtype).view(b.shape))
+                off += nb
 
     def average_(self, t):
-        if self.world == 1:
+        if not self.enabled:
             return
         if self.backend == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
@@ -91,5 +104,5 @@ class DataParallelComm:
     def reduce_bucket(self, seg):
         """C2: average the gradient range completed by backward segment `seg` (no-op if none)."""
         r = self.buckets.get(seg)
-        if r is not None and self.world > 1:
+        if r is not None and self.enabled:
             self.average_(self.arena.g[r[0]:r[1]])

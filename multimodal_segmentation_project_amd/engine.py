@@ -59,7 +59,10 @@ def build_desc(model, x, dtype):
         raise _lib.Mi3dError(f"input has {x.shape[1]} channels, model expects {d.in_channels}")
     d.dtype = _lib.dtype_code(dtype)
     bn = model.encoder[0].double_conv[1]
-    d.bn_momentum = 0.1 if bn.momentum is None else bn.momentum
+    if bn.momentum is None:
+        raise _lib.Mi3dError("BatchNorm3d(momentum=None) (cumulative moving average) is not supported; the reference "
+                             "uses the default momentum 0.1 (models/unet.py:12,16)")
+    d.bn_momentum = bn.momentum
     d.bn_eps = bn.eps
     return d
 
@@ -117,6 +120,11 @@ class _UNetFn(torch.autograd.Function):
         x, *params = ctx.saved_tensors
         if dlogits is None and dgap is None:
             return (None, None, None) + (None,) * len(params)
+        if not hold.training:
+            # the backward kernels implement train-mode BatchNorm (batch statistics); an eval-mode forward normalised
+            # with running statistics, whose gradient is a different formula
+            raise _lib.Mi3dError("backward through a UNet3D forward that ran in eval mode is not supported: call "
+                                 "model.train() (train_unet.py:208) or wrap evaluation in torch.no_grad()")
         if dlogits is not None:
             dlogits = dlogits.contiguous().float()
         if dgap is not None:

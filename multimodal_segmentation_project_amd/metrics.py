@@ -132,14 +132,21 @@ import weakref
 _cache = {"pred": None, "target": None, "ver": None, "val": None}
 
 
+def _cache_key(pred, target):
+    # tensor versions catch torch-side writes; the library launch counter catches raw C calls (hipGraph replays, the
+    # TrainStep's static logits buffer) that rewrite a buffer without bumping its torch version
+    return (pred._version, target._version, pred.data_ptr(), target.data_ptr(), _lib.launches)
+
+
 def calculate_all(pred, target):
     """(iou, dice, accuracy) as a float32 tensor[3] from ONE argmax+count pass [utils/metrics.py:65-129].
     The reference's three functions are called back to back on the same tensors (train_unet.py:229-232); the
-    result is shared between them while BOTH tensor objects are alive and unmodified (identity + version check)."""
+    result is shared between them while BOTH tensor objects are alive and unmodified: identity + torch version + no
+    library call in between (a raw C call or graph replay may rewrite a buffer without bumping its version)."""
     n, c, v, labels = _prep(pred, target)
     cp = _cache["pred"]() if _cache["pred"] is not None else None
     ct = _cache["target"]() if _cache["target"] is not None else None
-    if cp is pred and ct is target and _cache["ver"] == (pred._version, target._version):
+    if cp is pred and ct is target and _cache["ver"] == _cache_key(pred, target):
         return _cache["val"]
     p32 = pred.detach().contiguous().float()
     d = pred.shape[2] if pred.dim() > 2 else 1      # reference loop bound: first spatial dim after argmax
@@ -147,7 +154,7 @@ def calculate_all(pred, target):
     ws = torch.empty(_lib.lib().mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=pred.device)
     call("mi3d_seg_metrics", ptr(p32), ptr(labels), n, c, d, v, ptr(out), ptr(ws), stream_ptr())
     _cache["pred"], _cache["target"] = weakref.ref(pred), weakref.ref(target)
-    _cache["ver"], _cache["val"] = (pred._version, target._version), out
+    _cache["ver"], _cache["val"] = _cache_key(pred, target), out
     return out
 
 

@@ -1,99 +1,149 @@
-"""TrainStep — the reference's per-step hot loop (train_unet.py:220-252, distill_unet.py:107-133) as a native,
-hipGraph-capturable kernel sequence with data-parallel gradient all-reduce over RCCL.
+"""TrainStep / DannStep — the reference's per-step hot loops as native, hipGraph-capturable kernel sequences with
+data-parallel gradient all-reduce over RCCL.
 
-    zero_grad -> model(images) -> loss_fn -> backward(loss/accum) -> [all-reduce grads / world] -> AdamW.step
-    -> calculate_{iou,dice,accuracy} -> gather(loss, iou, dice, acc).mean()
+    TrainStep   train_unet.py:220-252 (== finetune_ct.py:159-191), distill_unet.py:107-133
+        zero_grad -> model(images) -> loss_fn -> backward(loss/accum) -> [all-reduce grads / world] -> AdamW.step
+        -> calculate_{iou,dice,accuracy} -> gather(loss, iou, dice, acc).mean()
+    DannStep    train_dann.py:233-300
+        source fwd -> target fwd (full net) -> GAP x2 -> grad_reverse x2 -> discriminator -> CE
+        -> total = task + lambda*domain (lambda applied twice, Q3) -> ONE backward over both graphs -> two AdamW steps
 
 Design (MI355X-first, not a DDP translation):
-  * parameters, gradients and AdamW moments live in four flat fp32 arenas (22.6 MB each); nn.Parameters are
-    views, so state_dict()/load_state_dict()/torch optimizers keep working, while the optimizer is ONE kernel
-    and gradient all-reduce operates on contiguous arena ranges (no bucket copy-in/copy-out).
-  * backward runs as 2L+2 C calls (segments); after the decoder, the bottleneck and encoder.L-1 segments the
-    finished arena range is all-reduced on a side stream (RCCL over xGMI) while the remaining, bandwidth-heavy
-    full-resolution encoder backward runs (82 % of gradient bytes are ready mid-backward).
-  * BatchNorm statistics are per-GPU local (DDP + BatchNorm3d semantics); the per-forward buffer broadcast of
-    DDP is replaced by `sync_buffers()` before eval/checkpoint; the four scalar gathers (C4) are
-    one 4-float all-reduce.
+  * parameters, gradients and AdamW moments live in flat fp32 arenas (22.6 MB each); nn.Parameters are views, so
+    state_dict()/load_state_dict() keep working, while the optimizer is ONE kernel and gradient all-reduce operates
+    on contiguous arena ranges (no bucket copy-in/copy-out).
+  * backward runs as runs of segments; after the decoder, the bottleneck and encoder.L-1 segments the finished arena
+    range is all-reduced on a side stream (RCCL over xGMI) while the remaining, bandwidth-heavy full-resolution encoder
+    backward runs (82 % of gradient bytes are ready mid-backward).  The four scalar gathers of the reference
+    (C4) are one 4-float all-reduce launched right after the loss kernel, hidden under the whole backward.
+  * a step is captured into hipGraphs: ONE graph at world 1; at world > 1 one graph per comm-free run of kernels with
+    the all-reduces launched between them (RCCL calls stay outside the graphs).
+  * BatchNorm statistics are per-GPU local (DDP + BatchNorm3d semantics); the per-forward buffer broadcast of DDP
+     is replaced by `sync_buffers()` before eval/checkpoint.
   * no host synchronisation inside step(); results are device tensors.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
 
 from . import _lib, engine
-from ._lib import LossCfg, call, ptr, ptr_table, stream_ptr
+from ._lib import Mi3dError, call, ptr, ptr_table, stream_ptr
 from . import metrics as M
 from .dp import DataParallelComm, ParamArena
+
+_LOSS_TABLE = {      # name -> (w_ce, region_kind, w_reg, alpha, beta, eps); train_unet.py:178-205
+    "combined": (1.0, 1, 1.0, 0.0, 0.0, 1e-5), "dice": (0.0, 1, 1.0, 0.0, 0.0, 1e-5),
+    "tversky": (0.0, 2, 1.0, 0.5, 0.5, 1e-6), "ce_tversky": (0.3, 2, 0.7, 0.5, 0.5, 1e-6),
+    "ce": (1.0, 0, 0.0, 0.0, 0.0, 1e-6),
+}
 
 
 def _loss_cfg(kind, kd_alpha=None, temperature=2.0):
     if kd_alpha is not None:      # distillation_loss, utils/metrics.py:169-190
         return M._cfg(0.3 * kd_alpha, 2, 0.7 * kd_alpha, 0.7, 0.3, 1e-6, 1.0 - kd_alpha, temperature)
-    table = {
-        "combined": (1.0, 1, 1.0, 0.0, 0.0, 1e-5), "dice": (0.0, 1, 1.0, 0.0, 0.0, 1e-5),
-        "tversky": (0.0, 2, 1.0, 0.5, 0.5, 1e-6), "ce_tversky": (0.3, 2, 0.7, 0.5, 0.5, 1e-6),
-        "ce": (1.0, 0, 0.0, 0.0, 0.0, 1e-6),
-    }
-    return M._cfg(*table.get(kind, table["combined"]))
+    if kind not in _LOSS_TABLE:
+        raise Mi3dError(f"unknown loss {kind!r}: one of {sorted(_LOSS_TABLE)} (train_unet.py:538 --loss choices)")
+    return M._cfg(*_LOSS_TABLE[kind])
 
 
-class TrainStep:
-    def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
-                 grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
-                 compute_dtype=None, use_graph=False, two_stream=False):
+class ArenaAdamW(torch.optim.Optimizer):
+    """`param_groups` surface of the arena optimizer, so that torch.optim.lr_scheduler objects (the reference's
+    ReduceLROnPlateau(mode='max', patience=10, factor=0.1, min_lr=1e-6), train_unet.py:381,442) can drive the learning
+    rate: `scheduler = ReduceLROnPlateau(step.optimizer, ...); scheduler.step(val_dice)`.  The update itself is the
+    fused kernel inside TrainStep.step(); calling .step() here is an error."""
+
+    def __init__(self, params, lr, betas, eps, weight_decay):
+        super().__init__(list(params), dict(lr=float(lr), betas=tuple(betas), eps=float(eps),
+                                            weight_decay=float(weight_decay)))
+
+    def step(self, closure=None):
+        raise Mi3dError("ArenaAdamW.step(): the AdamW update runs inside TrainStep.step() / DannStep.step()")
+
+
+class _Graphs:
+    """hipGraph executables of one static state: variant -> [(graph_exec, comm_fn_or_None), ...]"""
+
+    def __init__(self):
+        self.by_variant = {}
+        self.hyper = None
+
+    def drop(self):
+        for segs in self.by_variant.values():
+            for g, _ in segs:
+                if g is not None and g.value:
+                    _lib.lib().mi3d_graph_destroy(g)
+        self.by_variant = {}
+
+
+class _StepBase:
+    """Arena / communication / graph machinery shared by TrainStep and DannStep."""
+
+    def _init_common(self, model, lr, weight_decay, betas, eps, grad_accum, process_group, compute_dtype, use_graph,
+                     force_comm):
         self.model = model
-        self.teacher = kd_teacher
-        self.cfg = _loss_cfg(loss, kd_alpha if kd_teacher is not None else None, kd_temperature)
-        self._graph = None
-        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.accum = int(grad_accum)
+        if self.accum < 1:
+            raise Mi3dError("grad_accum must be >= 1")
         self.micro = 0
         self.dtype = compute_dtype
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.device = next(model.parameters()).device
-        _lib.require_cuda(next(model.parameters()), "TrainStep")
+        p0 = next(model.parameters())
+        _lib.require_cuda(p0, type(self).__name__)
+        self.device = p0.device
         self.arena = ParamArena(model.parameters(), self.device)
+        self.optimizer = ArenaAdamW(model.parameters(), lr, betas, eps, weight_decay)
         n_levels = len(model.encoder)
-        self.comm = DataParallelComm(self.arena, n_levels, process_group)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
-        # second compute stream: weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
-        self.aux_stream = torch.cuda.Stream(device=self.device) if two_stream else None
-        self._events = None
-        if two_stream:
-            evs = []
-            for _ in range(4):
-                e = C.c_void_p()
-                call("mi3d_event_create", C.byref(e))
-                evs.append(e.value)
-            self._events = ptr_table(evs)
-        self.use_graph = bool(use_graph) and self.world == 1
-        self._graph = None
+        # MI3D_FORCE_COMM=1 / force_comm: drive the bucket path (side stream, all-reduce, joins, segmented graphs) even
+        # at world 1 -- a 1-rank RCCL group on the 1-GPU box exercises the real code path
+        self.force_comm = bool(force_comm) or os.environ.get("MI3D_FORCE_COMM", "0") == "1"
+        self.do_comm = self.world > 1 or (self.force_comm and dist.is_available() and dist.is_initialized())
+        self.comm = DataParallelComm(self.arena, n_levels, process_group, force=self.do_comm)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.do_comm else None
+        self.use_graph = bool(use_graph)
+        self._statics = {}
         self._static = None
         self.inv_accum = torch.full((), 1.0 / self.accum, dtype=torch.float32, device=self.device)
-        if self.world > 1:
-            self.broadcast_parameters()
+        self._closed = False
 
+    # ---- optimizer surface
     @property
     def lr(self):
-        return self._lr
+        return self.optimizer.param_groups[0]["lr"]
 
     @lr.setter
     def lr(self, value):
-        """Learning rate (ReduceLROnPlateau of train_unet.py:381,442 is host policy: assign the new value here).  The
-        value is a kernel argument, so a captured step graph is dropped and re-captured on the next step."""
-        self._lr = float(value)
-        self._graph = None
+        """Learning rate (also reachable through `self.optimizer.param_groups`, i.e. torch LR schedulers).  The value
+        is a kernel argument: captured step graphs are re-captured on the next step when it changed."""
+        for g in self.optimizer.param_groups:
+            g["lr"] = float(value)
 
-    def reset_optimizer(self):
-        """What rebuilding ``optim.AdamW`` does in the reference when the encoder is (un)frozen
-        (train_unet.py:413-431, finetune_ct.py:374-381): moments and step count start from zero."""
-        self.arena.m.zero_()
-        self.arena.v.zero_()
-        self.arena.step.zero_()
-        self._graph = None
-        self._static = None
+    def _hyper(self):
+        g = self.optimizer.param_groups[0]
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+
+    def _drop_graphs(self):
+        for st in self._statics.values():
+            st["graphs"].drop()
+
+    def close(self):
+        """Destroy captured graph executables and events (also run by __del__)."""
+        if getattr(self, "_closed", True):
+            return
+        self._closed = True
+        try:
+            self._drop_graphs()
+            self._close_extra()
+        except Exception:      # noqa: BLE001  (interpreter shutdown: the library may already be gone)
+            pass
+
+    def _close_extra(self):
+        pass
+
+    def __del__(self):
+        self.close()
 
     # ---- DDP construction semantics: rank 0's parameters and buffers win
     def broadcast_parameters(self):
@@ -102,20 +152,189 @@ class TrainStep:
     def sync_buffers(self):
         self.comm.sync_buffers(self.model.buffers())
 
-    # ---- static state for one (shape, dtype)
-    def _prepare(self, x):
+    # ---- exchange points
+    def _on_comm_stream(self, fn):
+        """Run fn on the communication stream, ordered after everything enqueued so far on the compute stream; the
+        compute stream keeps going."""
+        cs = self.comm_stream
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            fn()
+
+    def _join_comm(self):
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _adamw(self, arena, ranges, hyper, s):
+        lr, b1, b2, eps, wd = hyper
+        for k, (lo, hi) in enumerate(ranges):
+            call("mi3d_adamw_apply", arena.p.data_ptr() + 4 * lo, arena.g.data_ptr() + 4 * lo,
+                 arena.m.data_ptr() + 4 * lo, arena.v.data_ptr() + 4 * lo, hi - lo, lr, b1, b2, eps, wd, 1.0,
+                 ptr(arena.step), int(k == len(ranges) - 1), s)
+
+    @staticmethod
+    def _trainable_ranges(arena, trainable):
+        ranges = []
+        for i, t in enumerate(trainable):
+            if not t:
+                continue
+            lo, hi = arena.range_of(i, i + 1)
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1] = (ranges[-1][0], hi)
+            else:
+                ranges.append((lo, hi))
+        return ranges
+
+    # ---- graph capture / replay.  `variant` = (first micro-step of an accumulation window, boundary micro-step)
+    def _variant(self):
+        return (self.micro % self.accum == 0, (self.micro + 1) % self.accum == 0)
+
+    def _run(self, st):
+        variant = self._variant()
+        if not self.use_graph:
+            self._enqueue(st, variant, lambda fn: fn())
+            self.micro += 1
+            return
+        gr = st["graphs"]
+        hyper = self._hyper()
+        if gr.hyper != hyper:
+            gr.drop()
+            gr.hyper = hyper
+        segs = gr.by_variant.get(variant)
+        if segs is None:
+            segs = gr.by_variant[variant] = self._capture(st, variant)
+        for g, fn in segs:
+            call("mi3d_graph_launch", g, stream_ptr())
+            if fn is not None:
+                fn()
+        self.micro += 1
+
+    def _mutable_state(self):
+        """Tensors a step execution modifies (snapshot/restore around the capture warm-up)."""
+        a = self.arena
+        return [a.p, a.g, a.m, a.v, a.step] + list(self.model.buffers()) + [engine._rng_state(self.model, self.device)]
+
+    def _capture(self, st, variant):
+        """Capture one micro-step into hipGraph(s).  A warm-up execution is needed first (lazy code-object loading
+        must not happen inside the capture); it runs on a snapshot of all mutable state, which is restored afterwards,
+        so capturing is invisible to the training trajectory.  Communication functions are not captured: they cut the
+        graph, and replay launches them between the segments."""
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        segs = []
+        with torch.cuda.stream(s):
+            state = self._mutable_state()
+            snap = [t.clone() for t in state]
+            self._enqueue(st, variant, lambda fn: fn())
+            if self.do_comm:
+                self._join_comm()
+                self.comm_stream.synchronize()
+            s.synchronize()
+            for t, c in zip(state, snap):
+                t.copy_(c)
+            s.synchronize()
+
+            def cut(fn):
+                g = C.c_void_p()
+                call("mi3d_graph_end", s.cuda_stream, C.byref(g))
+                segs.append((g, fn))
+                call("mi3d_graph_begin", s.cuda_stream)
+
+            call("mi3d_graph_begin", s.cuda_stream)
+            try:
+                self._enqueue(st, variant, cut)
+            finally:
+                g = C.c_void_p()
+                call("mi3d_graph_end", s.cuda_stream, C.byref(g))
+                segs.append((g, None))
+        torch.cuda.current_stream().wait_stream(s)
+        return segs
+
+
+class TrainStep(_StepBase):
+    def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
+                 grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
+                 compute_dtype=None, use_graph=False, two_stream=False, reference_zero_grad_quirk=False,
+                 force_comm=False):
+        """reference_zero_grad_quirk: train_unet.py:222 / finetune_ct.py:161 call optimizer.zero_grad() INSIDE
+        accelerator.accumulate(), where accelerate only really zeroes on the boundary micro-step -> the gradient the
+        reference applies is grad(last micro-batch)/accum.  False (default): accumulate all micro-batches
+        (what distill_unet.py:114-115 does and what the flag's name promises); True: reproduce the reference's
+        train/finetune behaviour bit for bit (non-boundary micro-steps still run forward, BN statistics and metrics)."""
+        cfg = _loss_cfg(loss, kd_alpha if kd_teacher is not None else None, kd_temperature)     # validates the name first
+        self._init_common(model, lr, weight_decay, betas, eps, grad_accum, process_group, compute_dtype, use_graph,
+                          force_comm)
+        self.teacher = kd_teacher
+        self.loss_kind = loss
+        self.cfg = cfg
+        # evaluate(): train_unet.py:259-305 uses the training loss_fn; distill_unet.py:149 uses combined_loss
+        self.eval_cfg = _loss_cfg("combined" if kd_teacher is not None else loss)
+        self.quirk = bool(reference_zero_grad_quirk) and kd_teacher is None
+        if kd_teacher is not None:
+            self._check_teacher(kd_teacher)
+        # second compute stream: weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
+        self.aux_stream = torch.cuda.Stream(device=self.device) if two_stream else None
+        self._events = None
+        self._event_handles = []
+        if two_stream:
+            for _ in range(4):
+                e = C.c_void_p()
+                call("mi3d_event_create", C.byref(e))
+                self._event_handles.append(e.value)
+            self._events = ptr_table(self._event_handles)
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    def _close_extra(self):
+        for e in self._event_handles:
+            _lib.lib().mi3d_event_destroy(e)
+        self._event_handles = []
+
+    def _check_teacher(self, teacher):
+        """distill_unet.py:20-29 loads the teacher with map_location: it must end up on the student's device with
+        the student's architecture, else the kernels would dereference foreign addresses."""
+        sp, tp = list(self.model.parameters()), list(teacher.parameters())
+        sb, tb = list(self.model.buffers()), list(teacher.buffers())
+        if len(sp) != len(tp) or len(sb) != len(tb):
+            raise Mi3dError(f"kd_teacher has {len(tp)} parameters / {len(tb)} buffers, the student {len(sp)} / {len(sb)}: "
+                            "teacher and student must be the same UNet3D architecture (distill_unet.py:214-215)")
+        for kind, mine, theirs in (("parameter", sp, tp), ("buffer", sb, tb)):
+            for i, (a, b) in enumerate(zip(mine, theirs)):
+                if b.device != self.device:
+                    raise Mi3dError(f"kd_teacher {kind} {i} is on {b.device}, the student on {self.device}: move the "
+                                    "teacher with .to(device) first (no CPU fallback)")
+                if tuple(a.shape) != tuple(b.shape) or a.dtype != b.dtype:
+                    raise Mi3dError(f"kd_teacher {kind} {i}: shape/dtype {tuple(b.shape)}/{b.dtype} != student's "
+                                    f"{tuple(a.shape)}/{a.dtype}")
+                if not b.is_contiguous():
+                    raise Mi3dError(f"kd_teacher {kind} {i} is not contiguous")
+
+    def reset_optimizer(self):
+        """What rebuilding ``optim.AdamW`` does in the reference when the encoder is (un)frozen
+        (train_unet.py:413-431, finetune_ct.py:374-381): moments and step count start from zero."""
+        self.arena.m.zero_()
+        self.arena.v.zero_()
+        self.arena.step.zero_()
+        self._drop_graphs()
+        self._statics = {}
+        self._static = None
+
+    # ---- static state for one (shape, dtype, trainable set, mode)
+    def _prepare(self, x, mode="train"):
         dt = self.dtype or engine.resolve_compute_dtype(self.model)
-        desc = engine.build_desc(self.model, x, dt)
         # frozen parameters (requires_grad=False: encoder/bottleneck freezing of train_unet.py:31-43, finetune_ct.py:270-304)
         # are part of the static state: they get no gradient, no optimizer update, and trailing all-frozen backward
         # segments are not run at all
         trainable = tuple(bool(p.requires_grad) for p in self.arena.params)
-        key = (tuple(x.shape), dt, trainable)
-        if self._static is not None and self._static["key"] == key:
-            return self._static
+        key = (tuple(x.shape), dt, trainable, mode)
+        st = self._statics.get(key)
+        if st is not None:
+            if mode == "train":
+                self._static = st
+            return st
+        desc = engine.build_desc(self.model, x, dt)
         L = desc.n_levels
         lib = _lib.lib()
-        st = {"key": key, "desc": desc, "L": L, "trainable": trainable}
+        st = {"key": key, "desc": desc, "L": L, "trainable": trainable, "graphs": _Graphs()}
         st["ws_bytes"] = lib.mi3d_unet_workspace_bytes(C.byref(desc))
         if st["ws_bytes"] == 0:
             _lib.check(-1, "mi3d_unet_workspace_bytes")
@@ -125,62 +344,72 @@ class TrainStep:
         st["x"] = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)
         st["y"] = torch.empty((n, desc.D * desc.H * desc.W), dtype=torch.int64, device=dev)
         st["logits"] = torch.empty((n, c, desc.D, desc.H, desc.W), dtype=torch.float32, device=dev)
-        st["dlogits"] = torch.empty_like(st["logits"])
         st["loss"] = torch.empty((), dtype=torch.float32, device=dev)
         st["coef"] = torch.empty(_lib.LOSS_COEF_FLOATS, dtype=torch.float32, device=dev)
         st["loss_ws"] = torch.empty(lib.mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=dev)
         st["metrics"] = torch.empty(4, dtype=torch.float32, device=dev)       # loss, iou, dice, acc
         st["met_ws"] = torch.empty(lib.mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=dev)
-        st["ndrop"] = lib.mi3d_unet_dropout_count(C.byref(desc))
-        st["drop"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
         st["ptab"] = ptr_table([p.data_ptr() for p in self.arena.params])
-        st["gtab"] = ptr_table([gp if t else None for gp, t in zip(self.arena.grad_ptrs(), trainable)])
-        # contiguous trainable arena ranges for the optimizer, and the number of backward segments that still matter
-        a = self.arena
-        ranges = []
-        for i, t in enumerate(trainable):
-            if not t:
-                continue
-            lo, hi = a.range_of(i, i + 1)
-            if ranges and ranges[-1][1] == lo:
-                ranges[-1] = (ranges[-1][0], hi)
-            else:
-                ranges.append((lo, hi))
-        st["opt_ranges"] = ranges
-        nseg, last = 2 * L + 2, -1
-        r = (C.c_int * 4)()
-        for seg in range(nseg):
-            _lib.check(lib.mi3d_unet_segment_params(C.byref(desc), seg, r), "mi3d_unet_segment_params")
-            idx = list(range(r[0], r[1])) + (list(range(r[2], r[3])) if r[2] >= 0 else [])
-            if any(trainable[i] for i in idx):
-                last = seg
-        st["nseg_run"] = last + 1
         st["btab"] = ptr_table([b.data_ptr() for b in self.model.buffers()])
-        if self.teacher is not None:
-            st["t_ws"] = torch.empty(st["ws_bytes"], dtype=torch.uint8, device=dev)
-            st["t_logits"] = torch.empty_like(st["logits"])
-            st["t_ptab"] = ptr_table([p.data_ptr() for p in self.teacher.parameters()])
-            st["t_btab"] = ptr_table([b.data_ptr() for b in self.teacher.buffers()])
-        self._static = st
-        self._graph = None
+        if mode == "train":
+            st["dlogits"] = torch.empty_like(st["logits"])
+            st["ndrop"] = lib.mi3d_unet_dropout_count(C.byref(desc))
+            st["drop"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
+            st["gtab"] = ptr_table([gp if t else None for gp, t in zip(self.arena.grad_ptrs(), trainable)])
+            st["opt_ranges"] = self._trainable_ranges(self.arena, trainable)
+            nseg, last = 2 * L + 2, -1
+            r = (C.c_int * 4)()
+            seg_train = []
+            for seg in range(nseg):
+                _lib.check(lib.mi3d_unet_segment_params(C.byref(desc), seg, r), "mi3d_unet_segment_params")
+                idx = list(range(r[0], r[1])) + (list(range(r[2], r[3])) if r[2] >= 0 else [])
+                seg_train.append(any(trainable[i] for i in idx))
+                if seg_train[-1]:
+                    last = seg
+            st["nseg_run"] = last + 1
+            # exchange schedule: bucket -> the segment after which it is complete AND will still be run; buckets with
+            # no trainable parameter are not reduced at all
+            sched = {}
+            for seg, (lo, hi) in self.comm.buckets.items():
+                live = any(t and lo <= o < hi for o, t in zip(self.arena.offsets, trainable))
+                if live and last >= 0:
+                    sched.setdefault(min(seg, last), []).append(seg)
+            st["comm_after"] = sched
+            if self.teacher is not None:
+                st["t_ws"] = torch.empty(st["ws_bytes"], dtype=torch.uint8, device=dev)
+                st["t_logits"] = torch.empty_like(st["logits"])
+                st["t_ptab"] = ptr_table([p.data_ptr() for p in self.teacher.parameters()])
+                st["t_btab"] = ptr_table([b.data_ptr() for b in self.teacher.buffers()])
+            self._static = st
+        self._statics[key] = st
         return st
 
     # ---- the kernel sequence of one micro-step (everything on the current stream except the all-reduces)
-    def _enqueue(self, st):
-        desc, L = st["desc"], st["L"]
+    def _enqueue(self, st, variant, comm):
+        first, boundary = variant
+        desc = st["desc"]
         s = stream_ptr()
         model = self.model
-        boundary = (self.micro + 1) % self.accum == 0
-        # Q2: train_unet.py:222 zeroes inside accumulate() -> only the boundary micro-batch's gradient
-        # survives; distillation (distill_unet.py:114-115) accumulates properly.  We accumulate properly in both
-        # and document the reference quirk instead of reproducing a bug.
-        accumulate = 0 if self.micro % self.accum == 0 else 1
+        if not model.training:
+            raise Mi3dError("TrainStep.step() on a model in eval mode: the backward kernels use batch statistics "
+                            "(train_unet.py:208 calls model.train() first); use evaluate() for eval-mode passes")
+        # Q2: see reference_zero_grad_quirk in __init__
+        if self.quirk:
+            accumulate, run_backward = 0, boundary
+        else:
+            accumulate, run_backward = (0 if first else 1), True
         drop = None
         p = float(getattr(model, "dropout_rate", 0.0))
-        if model.training and p > 0.0:
+        injected = getattr(model, "_mi3d_injected_drop_scales", None)
+        if injected is not None:
+            if injected.numel() != st["ndrop"]:
+                raise Mi3dError(f"injected dropout scales have {injected.numel()} entries, plan needs {st['ndrop']}")
+            st["drop"].copy_(injected.reshape(-1).to(self.device))
+            drop = st["drop"]
+        elif p > 0.0:
             call("mi3d_dropout_scales", ptr(st["drop"]), st["ndrop"], p, ptr(engine._rng_state(model, self.device)), s)
             drop = st["drop"]
-        call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), int(model.training),
+        call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1,
              ptr(st["logits"]), None, ptr(st["ws"]), st["ws_bytes"], s)
         t_logits = None
         if self.teacher is not None:
@@ -192,41 +421,33 @@ class TrainStep:
         call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, desc.D, v,
              C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
              ptr(st["met_ws"]), s)
-        call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
-             ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
-        nseg = st["nseg_run"]
-        do_comm = self.world > 1 and boundary
-        aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
-        # one C call per run of segments between exchange steps: kernels of adjacent segments share launches (a
-        # weight-gradient slab sum rides in the next BatchNorm reduction), which a call boundary would cut
-        start = 0
-        for seg in range(nseg):
-            last = seg == nseg - 1
-            if last or (do_comm and seg in self.comm.buckets):
-                call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
-                     ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
-                     self._events)
-                start = seg + 1
-                if do_comm and seg in self.comm.buckets:
-                    self._allreduce_bucket(seg)
-        if do_comm:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.do_comm:
+            # the four scalar gathers fused into one 4-float all-reduce, in flight under the whole backward
+            met = st["metrics"]
+            comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
+        if run_backward:
+            call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
+                 ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
+            nseg = st["nseg_run"]
+            do_comm = self.do_comm and boundary
+            aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
+            # one C call per run of segments between exchange steps: kernels of adjacent segments share launches (a
+            # weight-gradient slab sum rides in the next BatchNorm reduction), which a call boundary would cut
+            start = 0
+            for seg in range(nseg):
+                last = seg == nseg - 1
+                exch = st["comm_after"].get(seg) if do_comm else None
+                if last or exch:
+                    call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
+                         ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
+                         self._events)
+                    start = seg + 1
+                    if exch:
+                        comm(lambda b=tuple(exch): self._on_comm_stream(lambda: [self.comm.reduce_bucket(k) for k in b]))
+        if self.do_comm:
+            comm(self._join_comm)
         if boundary:
-            a = self.arena
-            rng = st["opt_ranges"]
-            for k, (lo, hi) in enumerate(rng):
-                call("mi3d_adamw_apply", a.p.data_ptr() + 4 * lo, a.g.data_ptr() + 4 * lo, a.m.data_ptr() + 4 * lo,
-                     a.v.data_ptr() + 4 * lo, hi - lo, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, 1.0,
-                     ptr(a.step), int(k == len(rng) - 1), s)
-        self.micro += 1
-
-    def _allreduce_bucket(self, seg):
-        """Average one finished gradient range over ranks on the communication stream, ordered after the kernels
-        enqueued so far; the compute stream keeps running the remaining backward segments."""
-        cs = self.comm_stream
-        cs.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cs):
-            self.comm.reduce_bucket(seg)
+            self._adamw(self.arena, st["opt_ranges"], self._hyper(), s)
 
     def step(self, images, labels):
         """One micro-step on (images (N,Cin,D,H,W) float, labels (N,1,D,H,W) int64).  Returns a device float32[4]
@@ -240,15 +461,8 @@ class TrainStep:
         """Run on the data already resident in the static buffers (bench path: inputs in HBM when timing starts)."""
         st = self._static
         if st is None:
-            raise _lib.Mi3dError("step_static() before any step()/load_batch()")
-        if self.use_graph and self.accum == 1:
-            if self._graph is None:
-                self._capture(st)
-            call("mi3d_graph_launch", self._graph, stream_ptr())
-            self.micro += 1
-        else:
-            self._enqueue(st)
-        self.comm.average_(st["metrics"])     # SURVEY C4: the four scalar gathers fused into one 4-float all-reduce
+            raise Mi3dError("step_static() before any step()/load_batch()")
+        self._run(st)
         return st["metrics"]
 
     def load_batch(self, images, labels):
@@ -256,41 +470,13 @@ class TrainStep:
         st["x"].copy_(images)
         st["y"].copy_(labels.reshape(st["y"].shape))
 
-    def _capture(self, st):
-        """Capture one micro-step into a hipGraph.  A warm-up execution is needed first (lazy code-object loading must
-        not happen inside the capture); it runs on a snapshot of all mutable state, which is restored afterwards, so
-        capturing is invisible to the training trajectory."""
-        s = torch.cuda.Stream(device=self.device)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            a = self.arena
-            snap = [t.clone() for t in (a.p, a.g, a.m, a.v, a.step)]
-            bufs = [b.clone() for b in self.model.buffers()]
-            rng = engine._rng_state(self.model, self.device).clone()
-            micro = self.micro
-            self._enqueue(st)
-            s.synchronize()
-            for t, c in zip((a.p, a.g, a.m, a.v, a.step), snap):
-                t.copy_(c)
-            for b, c in zip(self.model.buffers(), bufs):
-                b.copy_(c)
-            engine._rng_state(self.model, self.device).copy_(rng)
-            self.micro = micro
-            s.synchronize()
-            call("mi3d_graph_begin", s.cuda_stream)
-            try:
-                self._enqueue(st)
-            finally:
-                g = C.c_void_p()
-                call("mi3d_graph_end", s.cuda_stream, C.byref(g))
-            self._graph = g
-            self.micro = micro             # the captured enqueue did not execute
-        torch.cuda.current_stream().wait_stream(s)
-
     @torch.no_grad()
     def evaluate(self, images, labels):
-        """model.eval() forward + loss + metrics (train_unet.py:259-305); returns device float32[4]."""
-        st = self._prepare(images)
+        """model.eval() forward + loss + metrics (train_unet.py:259-305: the TRAINING loss_fn; distill_unet.py:136-160:
+        combined_loss), averaged over ranks like the reference's gather().mean(); returns device float32[4].  Has its own
+        static state: a validation batch of another shape (the reference validates with batch 1) does not disturb the
+        captured training graph."""
+        st = self._prepare(images, mode="eval")
         st["x"].copy_(images)
         st["y"].copy_(labels.reshape(st["y"].shape))
         desc = st["desc"]
@@ -298,9 +484,261 @@ class TrainStep:
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
         call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], None, 0, ptr(st["logits"]), None,
              ptr(st["ws"]), st["ws_bytes"], s)
-        cfg = _loss_cfg("combined")
-        call("mi3d_seg_loss_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, v, C.byref(cfg), ptr(st["metrics"]),
-             ptr(st["coef"]), ptr(st["loss_ws"]), s)
-        call("mi3d_seg_metrics", ptr(st["logits"]), ptr(st["y"]), n, c, desc.D, v, ptr(st["metrics"][1:]),
+        call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
+             C.byref(self.eval_cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
              ptr(st["met_ws"]), s)
-        return st["metrics"].clone()
+        out = st["metrics"].clone()
+        self.comm.average_(out)
+        return out
+
+
+class DannStep(_StepBase):
+    """Native DANN micro-step (train_dann.py:233-300), single-GPU or data-parallel.
+
+    Kernel sequence: source forward (workspace A, GAP -> feat[0:N]) ; target forward (workspace B, the FULL net as the
+    reference runs it, Q4; GAP -> feat[N:2N]) ; loss + metrics on the source logits ; discriminator MLP forward on the
+    2N feature rows (rows are independent, so the reference's two calls are one) ; row CE with labels [0]*N + [1]*N ;
+    discriminator backward (its parameter gradients carry the lambda of `total = task + lambda*domain`) ; U-Net
+    backward of the source graph (dlogits and dgap, gap_scale = -lambda = the gradient reversal, so the encoder sees
+    -lambda^2 dL_dom/df, Q3) interleaved segment by segment with the backward of the target graph (dgap only:
+    bottleneck + encoder, accumulating into the same gradient arena) ; two arena AdamW updates.
+    Under DP the discriminator arena is one more bucket, in flight under the whole U-Net backward."""
+
+    def __init__(self, seg_model, disc_model, loss="ce_tversky", lambda_domain=0.1, lr=1e-3, weight_decay=0.01,
+                 betas=(0.9, 0.999), eps=1e-8, grad_accum=1, process_group=None, compute_dtype=None, use_graph=False,
+                 force_comm=False):
+        self._init_common(seg_model, lr, weight_decay, betas, eps, grad_accum, process_group, compute_dtype, use_graph,
+                          force_comm)
+        self.disc = disc_model
+        self.lam = float(lambda_domain)
+        self.cfg = _loss_cfg(loss)
+        self.eval_cfg = self.cfg
+        self.lins = [disc_model.net[0], disc_model.net[3], disc_model.net[6], disc_model.net[8]]
+        self.disc_p = [float(disc_model.net[2].p), float(disc_model.net[5].p)]
+        for p in disc_model.parameters():
+            _lib.require_cuda(p, "DannStep discriminator")
+        self.disc_arena = ParamArena(disc_model.parameters(), self.device)
+        # train_dann.py:421-422: both optimizers share lr / weight decay
+        self.disc_optimizer = ArenaAdamW(disc_model.parameters(), lr, betas, eps, weight_decay)
+        if self.world > 1:
+            self.broadcast_parameters()
+            dist.broadcast(self.disc_arena.p, src=0, group=process_group)
+
+    def _hyper(self):
+        g = self.disc_optimizer.param_groups[0]
+        return super()._hyper() + (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                   float(g["weight_decay"]))
+
+    def _mutable_state(self):
+        d = self.disc_arena
+        return super()._mutable_state() + [d.p, d.g, d.m, d.v, d.step, self._disc_rng()]
+
+    def _disc_rng(self):
+        st = getattr(self.disc, "_mi3d_rng_state", None)
+        if st is None or st.device != self.device:
+            st = torch.tensor([(torch.initial_seed() + 0x5DEECE66D) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
+                              device=self.device)
+            self.disc._mi3d_rng_state = st
+        return st
+
+    def _prepare(self, xs, xt):
+        if tuple(xs.shape) != tuple(xt.shape):
+            raise Mi3dError(f"source batch {tuple(xs.shape)} and target batch {tuple(xt.shape)} must have one shape "
+                            "(train_dann.py:399-400: both loaders use args.batch_size)")
+        dt = self.dtype or engine.resolve_compute_dtype(self.model)
+        trainable = tuple(bool(p.requires_grad) for p in self.arena.params)
+        key = (tuple(xs.shape), dt, trainable)
+        st = self._statics.get(key)
+        if st is not None:
+            self._static = st
+            return st
+        if not all(trainable):
+            raise Mi3dError("DannStep: frozen segmentation parameters are not supported")
+        desc = engine.build_desc(self.model, xs, dt)
+        lib = _lib.lib()
+        L = desc.n_levels
+        dev = self.device
+        st = {"key": key, "desc": desc, "L": L, "graphs": _Graphs()}
+        st["ws_bytes"] = lib.mi3d_unet_workspace_bytes(C.byref(desc))
+        if st["ws_bytes"] == 0:
+            _lib.check(-1, "mi3d_unet_workspace_bytes")
+        n, c = desc.N, desc.out_channels
+        F = 2 * desc.features[L - 1]
+        if self.lins[0].in_features != F:
+            raise Mi3dError(f"discriminator expects {self.lins[0].in_features} features, the bottleneck has {F}")
+        for k in ("ws_s", "ws_t"):
+            st[k] = torch.empty(st["ws_bytes"], dtype=torch.uint8, device=dev)
+        st["xs"] = torch.empty(tuple(xs.shape), dtype=torch.float32, device=dev)
+        st["xt"] = torch.empty(tuple(xs.shape), dtype=torch.float32, device=dev)
+        st["y"] = torch.empty((n, desc.D * desc.H * desc.W), dtype=torch.int64, device=dev)
+        st["logits"] = torch.empty((n, c, desc.D, desc.H, desc.W), dtype=torch.float32, device=dev)
+        st["logits_t"] = torch.empty_like(st["logits"])
+        st["dlogits"] = torch.empty_like(st["logits"])
+        st["coef"] = torch.empty(_lib.LOSS_COEF_FLOATS, dtype=torch.float32, device=dev)
+        st["loss_ws"] = torch.empty(lib.mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=dev)
+        st["met_ws"] = torch.empty(lib.mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=dev)
+        st["metrics"] = torch.empty(5, dtype=torch.float32, device=dev)       # task, iou, dice, acc, domain
+        st["ndrop"] = lib.mi3d_unet_dropout_count(C.byref(desc))
+        st["drop_s"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
+        st["drop_t"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
+        st["feat"] = torch.empty((2 * n, F), dtype=torch.float32, device=dev)
+        st["dfeat"] = torch.empty((2 * n, F), dtype=torch.float32, device=dev)
+        widths = [l.out_features for l in self.lins]
+        st["acts"] = [torch.empty((2 * n, w), dtype=torch.float32, device=dev) for w in widths]
+        st["gacts"] = [torch.empty((2 * n, w), dtype=torch.float32, device=dev) for w in widths]
+        st["lin_ws"] = torch.empty(2 * n * max(widths), dtype=torch.float32, device=dev)
+        st["ddrop"] = [torch.empty((2 * n, widths[i]), dtype=torch.float32, device=dev) for i in (0, 1)]
+        st["dlabels"] = torch.cat([torch.zeros(n, dtype=torch.int64), torch.ones(n, dtype=torch.int64)]).to(dev)
+        st["ptab"] = ptr_table([p.data_ptr() for p in self.arena.params])
+        st["gtab"] = ptr_table(self.arena.grad_ptrs())
+        st["btab"] = ptr_table([b.data_ptr() for b in self.model.buffers()])
+        st["opt_ranges"] = [(0, self.arena.numel)]
+        self._statics[key] = st
+        self._static = st
+        return st
+
+    def _enqueue(self, st, variant, comm):
+        first, boundary = variant
+        desc, L = st["desc"], st["L"]
+        s = stream_ptr()
+        seg, disc = self.model, self.disc
+        if not seg.training or not disc.training:
+            raise Mi3dError("DannStep.step() needs both models in train mode (train_dann.py:226-227)")
+        accumulate = 0 if first else 1
+        n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
+        lam = self.lam
+        # Dropout3d masks: one independent draw per forward (source, then target), like two module calls
+        p = float(getattr(seg, "dropout_rate", 0.0))
+        injected = getattr(seg, "_mi3d_injected_drop_scales", None)       # tests: (source scales, target scales)
+        drop_s = drop_t = None
+        if injected is not None:
+            st["drop_s"].copy_(injected[0].reshape(-1))
+            st["drop_t"].copy_(injected[1].reshape(-1))
+            drop_s, drop_t = st["drop_s"], st["drop_t"]
+        elif p > 0.0:
+            rng = engine._rng_state(seg, self.device)
+            call("mi3d_dropout_scales", ptr(st["drop_s"]), st["ndrop"], p, ptr(rng), s)
+            call("mi3d_dropout_scales", ptr(st["drop_t"]), st["ndrop"], p, ptr(rng), s)
+            drop_s, drop_t = st["drop_s"], st["drop_t"]
+        feat = st["feat"]
+        F = feat.shape[1]
+        call("mi3d_unet_forward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1,
+             ptr(st["logits"]), feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
+        call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab"], ptr(drop_t), 1,
+             ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], s)
+        call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
+             C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
+             ptr(st["met_ws"]), s)
+        call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), None, n, c, v, C.byref(self.cfg),
+             ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
+        # ---- discriminator on the 2N feature rows (train_dann.py:34-49,276-283)
+        dd = [None, None, None, None]
+        dinj = getattr(disc, "_mi3d_injected_drop_scales", None)          # tests: [mask after net.1, mask after net.4]
+        for i in (0, 1):
+            if dinj is not None:
+                st["ddrop"][i].copy_(dinj[i])
+                dd[i] = st["ddrop"][i]
+            elif self.disc_p[i] > 0.0:
+                call("mi3d_dropout_scales", ptr(st["ddrop"][i]), st["ddrop"][i].numel(), self.disc_p[i],
+                     ptr(self._disc_rng()), s)
+                dd[i] = st["ddrop"][i]
+        relus = (1, 1, 1, 0)
+        inp = feat
+        for i, l in enumerate(self.lins):
+            call("mi3d_linear_forward", ptr(inp), ptr(l.weight), ptr(l.bias), ptr(st["acts"][i]), 2 * n, l.in_features,
+                 l.out_features, relus[i], ptr(dd[i]), s)
+            inp = st["acts"][i]
+        # domain_loss = CE/accum (train_dann.py:283); its gradient enters `total` with weight lambda (:285)
+        call("mi3d_softmax_ce_rows", ptr(st["acts"][3]), ptr(st["dlabels"]), 2 * n, 2, ptr(st["metrics"][4:]),
+             ptr(st["gacts"][3]), lam / self.accum, s)
+        da = self.disc_arena
+        dgp = da.grad_ptrs()
+        for i in (3, 2, 1, 0):
+            l = self.lins[i]
+            x_in = feat if i == 0 else st["acts"][i - 1]
+            gx = st["dfeat"] if i == 0 else st["gacts"][i - 1]
+            call("mi3d_linear_backward", ptr(x_in), ptr(l.weight), ptr(st["acts"][i]), ptr(st["gacts"][i]), 2 * n,
+                 l.in_features, l.out_features, relus[i], ptr(dd[i]), ptr(gx), dgp[2 * i], dgp[2 * i + 1], accumulate, 1.0,
+                 ptr(st["lin_ws"]), s)
+        do_comm = self.do_comm and boundary
+        if self.do_comm:
+            met = st["metrics"]
+            comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
+        if do_comm:
+            dg = da.g
+            comm(lambda: self._on_comm_stream(lambda: self.comm.average_(dg)))
+        # ---- one backward over both graphs, segment by segment: gradient reversal = gap_scale -lambda
+        nseg = 2 * L + 2
+        dgs, dgt = st["dfeat"].data_ptr(), st["dfeat"].data_ptr() + 4 * n * F
+        start = 0
+        for sg in range(nseg):
+            last = sg == nseg - 1
+            exch = sg in self.comm.buckets and do_comm
+            if last or exch:
+                call("mi3d_unet_backward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s),
+                     ptr(st["dlogits"]), dgs, -lam, accumulate, start, sg + 1, ptr(st["ws_s"]), st["ws_bytes"], s, None, None)
+                t0 = max(start, L + 1)            # the target graph has no decoder part
+                if sg + 1 > t0:
+                    call("mi3d_unet_backward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["gtab"], ptr(drop_t),
+                         None, dgt, -lam, 1, t0, sg + 1, ptr(st["ws_t"]), st["ws_bytes"], s, None, None)
+                start = sg + 1
+                if exch:
+                    comm(lambda k=sg: self._on_comm_stream(lambda: self.comm.reduce_bucket(k)))
+        if self.do_comm:
+            comm(self._join_comm)
+        if boundary:
+            h = self._hyper()
+            self._adamw(self.arena, st["opt_ranges"], h[:5], s)
+            self._adamw(self.disc_arena, [(0, self.disc_arena.numel)], h[5:], s)
+
+    def load_batch(self, source_images, source_labels, target_images):
+        st = self._prepare(source_images, target_images)
+        st["xs"].copy_(source_images)
+        st["xt"].copy_(target_images)
+        st["y"].copy_(source_labels.reshape(st["y"].shape))
+
+    def step(self, source_images, source_labels, target_images, last_batch=False):
+        """One micro-step.  Returns device float32[5] = {task_loss, iou, dice, acc, domain_loss} (source-domain metrics,
+        train_dann.py:291-299; losses un-divided by the accumulation count like the reference's running sums).
+        last_batch: train_dann.py:287 also steps on the final batch of an epoch."""
+        st = self._prepare(source_images, target_images)
+        st["xs"].copy_(source_images, non_blocking=True)
+        st["xt"].copy_(target_images, non_blocking=True)
+        st["y"].copy_(source_labels.reshape(st["y"].shape), non_blocking=True)
+        return self.step_static(last_batch=last_batch)
+
+    def step_static(self, last_batch=False):
+        st = self._static
+        if st is None:
+            raise Mi3dError("step_static() before any step()/load_batch()")
+        if last_batch and (self.micro + 1) % self.accum != 0:
+            # force an optimizer step on this micro-batch, then start a fresh accumulation window
+            first = self.micro % self.accum == 0
+            if self.use_graph:
+                raise Mi3dError("last_batch with a partial accumulation window is not graph-captured; use use_graph=False")
+            self._enqueue(st, (first, True), lambda fn: fn())
+            self.micro += self.accum - (self.micro % self.accum)
+        else:
+            self._run(st)
+        out = st["metrics"]
+        return out
+
+    @torch.no_grad()
+    def evaluate(self, images, labels):
+        """train_dann.py:304-327: eval-mode source-domain validation with the training loss_fn."""
+        from . import unet_dann  # noqa: F401
+        was = self.model.training
+        self.model.eval()
+        try:
+            logits, _ = self.model(images, return_features=False)
+        finally:
+            self.model.train(was)
+        n, c, v, lab = M._prep(logits, labels)
+        out = torch.empty(4, dtype=torch.float32, device=self.device)
+        coef = torch.empty(_lib.LOSS_COEF_FLOATS, dtype=torch.float32, device=self.device)
+        lws = torch.empty(_lib.lib().mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=self.device)
+        mws = torch.empty(_lib.lib().mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=self.device)
+        call("mi3d_seg_loss_metrics_forward", ptr(logits), ptr(lab), None, n, c, logits.shape[2], v, C.byref(self.eval_cfg),
+             ptr(out), ptr(coef), ptr(out[1:]), ptr(lws), ptr(mws), stream_ptr())
+        self.comm.average_(out)
+        return out

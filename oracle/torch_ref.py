@@ -135,3 +135,38 @@ def dann_total_loss(seg_sd, disc_sd, xs, ys, xt, lam, kind="combined"):
     dl = F.cross_entropy(torch.cat([sp, tp]), torch.cat([torch.zeros(len(sp), dtype=torch.long),
                                                          torch.ones(len(tp), dtype=torch.long)]))
     return task + lam * dl, task, dl, up2, so
+
+
+def train_loop(sd, batches, accum=1, zero_grad_quirk=False, lr=1e-3, wd=0.01, kind="combined", metrics_fn=None):
+    """The step loop of train_unet.py:220-226 under accelerate's accumulate() (gradient_accumulation_steps = accum),
+    AdamW defaults of train_unet.py:378.  zero_grad_quirk=True is what the reference does in train_unet.py /
+    finetune_ct.py (optimizer.zero_grad() at the top of every micro-step is only honoured by accelerate on the boundary
+    micro-step: the earlier micro-batches' gradients are discarded); False accumulates all micro-batches
+    (distill_unet.py:114-115).  Returns (state_dict after the loop, per-micro-step losses, last gradients)."""
+    sd = {k: v.detach().clone() for k, v in sd.items()}
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    opt = torch.optim.AdamW([sd[k] for k in names], lr=lr, weight_decay=wd)
+    losses = []
+    for i, (x, y) in enumerate(batches):
+        boundary = (i + 1) % accum == 0
+        if (zero_grad_quirk and boundary) or (not zero_grad_quirk and i % accum == 0):
+            opt.zero_grad()
+        logits, _, updates = unet3d_forward(sd, x, train=True)
+        loss = seg_loss(logits, y, kind)
+        (loss / accum).backward()
+        for k, v in updates.items():
+            sd[k] = v
+        if boundary:
+            opt.step()
+        losses.append(float(loss))
+    grads = {k: (sd[k].grad.detach().clone() if sd[k].grad is not None else None) for k in names}
+    return {k: v.detach() for k, v in sd.items()}, losses, grads
+
+
+def plan_drop_scales(drop, n_levels):
+    """dict block-name -> (s1, s2) of (N, C)  ->  the flat layout of mi3d_unet_dropout_count (include/mi3d.h):
+    blocks [encoder.0..L-1, bottleneck, decoder.0..L-1], first then second Dropout3d of the block, each [N][C]."""
+    blocks = [f"encoder.{l}" for l in range(n_levels)] + ["bottleneck"] + [f"decoder.{i}" for i in range(n_levels)]
+    return torch.cat([drop[b][h].reshape(-1).float() for b in blocks for h in (0, 1)])

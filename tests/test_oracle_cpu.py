@@ -198,3 +198,71 @@ def test_torch_ref_default_unet_and_dann(golden):
     # conv biases in front of BN have roundoff-only gradients: compare the others relatively
     big = g["s16n2/grad_norms"] > 1e-6
     np.testing.assert_allclose(norms[big], g["s16n2/grad_norms"][big], rtol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------------ round 2
+def test_oracle_dropout_masks_match_reference(golden):
+    """oracle/torch_ref.unet3d_forward(drop_scales=...) replays the Dropout3d masks the REFERENCE drew (recorded by
+    forward hooks in tools/gen_golden.py::gen_dropout, p = 0.5, N = 3): logits, loss, every gradient, BN buffers."""
+    import torch
+    from oracle import torch_ref
+    g = golden("dropout")
+    sd = {k[len("small/sd0/"):]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("small/sd0/")}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    blocks = ["encoder.0", "encoder.1", "bottleneck", "decoder.0", "decoder.1"]
+    drop = {b: tuple(torch.from_numpy(g[f"small/mask/{b}.double_conv.{i}"]) for i in (3, 7)) for b in blocks}
+    for b in blocks:
+        for sc in drop[b]:
+            assert set(np.unique(sc.numpy()).tolist()) <= {0.0, 2.0}
+    logits, _, upd = torch_ref.unet3d_forward(sd, torch.from_numpy(g["small/x"]), train=True, drop_scales=drop)
+    loss = torch_ref.seg_loss(logits, torch.from_numpy(g["small/y"]), "combined")
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g["small/logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(loss), g["small/loss"], rtol=1e-6)
+    for k, v in sd.items():
+        if v.requires_grad:
+            np.testing.assert_allclose(v.grad.numpy(), g["small/grad/" + k], rtol=1e-3, atol=2e-6, err_msg=k)
+    for k, v in upd.items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), g["small/sd1/" + k], rtol=1e-5, atol=1e-6, err_msg=k)
+    flat = torch_ref.plan_drop_scales(drop, 2)
+    assert flat.numel() == 3 * 2 * (4 + 8 + 16 + 8 + 4)
+
+
+def test_oracle_loop_reproduces_reference_accumulation_quirk(golden):
+    """oracle/torch_ref.train_loop(zero_grad_quirk=True) == the reference's train_one_epoch executed under
+    Accelerator(gradient_accumulation_steps=2) (fixture loops.npz accum/*): only the boundary micro-batch's gradient is
+    applied; zero_grad_quirk=False (proper accumulation) gives different parameters."""
+    import torch
+    import multimodal_segmentation_project_amd as mi
+    from oracle import torch_ref
+    g = golden("loops")
+
+    def synth(n, s, seed, blocky):
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(n, 1, s, s, s, generator=gen)
+        y = torch.randint(0, 4, (n, 1, s, s, s), generator=gen)
+        if blocky:
+            zz, yy, xx = torch.meshgrid(torch.arange(s), torch.arange(s), torch.arange(s), indexing="ij")
+            lab = ((zz // (s // 4)) + (yy // (s // 4)) + (xx // (s // 4))) % 4
+            y = lab[None, None].expand(n, 1, s, s, s).contiguous().long()
+            x = y.float() / 3.0 + 0.1 * x
+        return x, y
+
+    batches = [synth(2, 16, 500 + i, i % 2 == 0) for i in range(4)]
+    torch.manual_seed(0)
+    sd0 = {k: v.detach().clone() for k, v in mi.UNet3D(1, 4, dropout_rate=0.0).state_dict().items()}
+    sd_q, losses, grads = torch_ref.train_loop(sd0, batches, accum=2, zero_grad_quirk=True)
+    np.testing.assert_allclose(np.mean(losses), g["accum/result"][0], rtol=1e-5)
+    keys = sorted(sd_q.keys())
+    dig = np.array([[float(sd_q[k].double().sum()), float(sd_q[k].double().abs().sum())] for k in keys])
+    sel = np.array([k.endswith(".weight") for k in keys])
+    np.testing.assert_allclose(dig[sel, 1], g["accum/param_digest_after"][sel, 1], rtol=1e-5)
+    for k, rn in zip(list(g["accum/grad_names"]), g["accum/grad_norms"]):
+        if rn > 1e-6:
+            assert abs(float(grads[k].double().norm()) - rn) / rn < 5e-3, k    # after one AdamW step: fp32 order noise
+    sd_p, _, _ = torch_ref.train_loop(sd0, batches, accum=2, zero_grad_quirk=False)
+    k = "decoder.3.double_conv.0.weight"
+    assert float((sd_p[k] - sd_q[k]).abs().max()) > 1e-4

@@ -371,20 +371,341 @@ def gen_distill(ref_unet, ref_metrics, out):
     np.savez_compressed(os.path.join(out, "distill.npz"), **d)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Round-2 fixtures: Dropout3d with real masks, the BASELINE configs at their real sizes (summaries only: losses,
+# metrics, gradient norms + leading slices, BN buffers, logit slices; each file a few hundred KB), the reference's
+# own step loops executed as they are (train_unet.train_one_epoch under accelerate's accumulate(): Q2;
+# train_dann.train_one_epoch_dann: two optimizers), and its evaluate().
+# ---------------------------------------------------------------------------------------------------------------
+# leading-index gradient slices incl. the level-4 tensors (bottleneck, decoder.0, upconvs.0) the round-1 SLICE_KEYS missed
+GRAD_SLICES = {
+    "encoder.0.double_conv.0.weight": None, "encoder.0.double_conv.4.weight": None, "encoder.1.double_conv.0.weight": 8,
+    "encoder.3.double_conv.4.weight": 1, "bottleneck.double_conv.0.weight": 2, "bottleneck.double_conv.4.weight": 1,
+    "bottleneck.double_conv.1.weight": None, "bottleneck.double_conv.1.bias": None, "bottleneck.double_conv.5.bias": None,
+    "upconvs.0.weight": 2, "upconvs.0.bias": None, "decoder.0.double_conv.0.weight": 1, "decoder.0.double_conv.4.weight": 2,
+    "decoder.0.double_conv.1.weight": None, "upconvs.3.weight": None, "upconvs.3.bias": None,
+    "decoder.3.double_conv.0.weight": None, "decoder.3.double_conv.4.weight": None, "decoder.3.double_conv.5.weight": None,
+    "decoder.3.double_conv.5.bias": None, "final_conv.weight": None, "final_conv.bias": None,
+}
+
+
+def _summ(d, pre, model, logits=None):
+    """Summary of a model after backward (+ maybe an optimizer step): gradient norms, leading slices, BN buffers."""
+    names = [k for k, _ in model.named_parameters()]
+    d[pre + "grad_names"] = np.array(names)
+    d[pre + "grad_norms"] = np.array([float(p.grad.double().norm()) if p.grad is not None else 0.0
+                                      for _, p in model.named_parameters()])
+    for k, p in model.named_parameters():
+        if k in GRAD_SLICES and p.grad is not None:
+            n = GRAD_SLICES[k]
+            d[pre + "grad/" + k] = npy(p.grad if n is None else p.grad[:n])
+    bn = {k: v for k, v in model.state_dict().items() if "running" in k}
+    d[pre + "bn_keys"] = np.array(sorted(bn.keys()))
+    d[pre + "bn_after"] = np.concatenate([npy(bn[k]).ravel() for k in sorted(bn.keys())])
+    if logits is not None:
+        s = logits.shape[-1]
+        a, b = s // 2 - 2, s // 2 + 2
+        d[pre + "logits_center"] = npy(logits[:, :, a:b, a:b, a:b])
+        d[pre + "logits_corner"] = npy(logits[:, :, :3, :3, :3])
+        d[pre + "logits_absmean"] = np.asarray(float(logits.double().abs().mean()))
+        d[pre + "logits_mean_per_class"] = npy(logits.double().mean(dim=(0, 2, 3, 4)))
+
+
+def _record_dropout_masks(model, cls):
+    """Forward hooks on every dropout module: mask scale per (n, c) = out/in (0 or 1/(1-p)).  Returns (handles, store);
+    store[name] is a list (one entry per forward call)."""
+    store, handles = {}, []
+
+    def mk(name):
+        def hook(mod, inp, out):
+            x, o = inp[0].detach(), out.detach()
+            if x.dim() == 5:
+                num, den = o.double().abs().sum(dim=(2, 3, 4)), x.double().abs().sum(dim=(2, 3, 4))
+            else:
+                num, den = o.double().abs(), x.double().abs()
+            keep = 1.0 / (1.0 - mod.p) if mod.p < 1 else 0.0
+            sc = torch.where(den > 0, num / den.clamp_min(1e-300), torch.full_like(den, float("nan")))
+            # entries whose input was all-zero are undetermined by out/in: any value reproduces the output
+            sc = torch.where(torch.isnan(sc), torch.full_like(sc, keep), sc)
+            store.setdefault(name, []).append(sc.float())
+        return hook
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, cls):
+            handles.append(mod.register_forward_hook(mk(name)))
+    return handles, store
+
+
+def gen_dropout(ref_unet, ref_metrics, out):
+    """Dropout3d with REAL masks (models/unet.py:14,18, p = 0.5 and the shipped 0.1): the masks the reference drew are
+    recorded by hooks, so the oracle / HIP path can replay them.  Complete small net (all grads) + default net summary."""
+    d = {}
+    torch.manual_seed(17)
+    m = ref_unet.UNet3D(in_channels=2, out_channels=3, features=[4, 8], dropout_rate=0.5)
+    g = torch.Generator().manual_seed(171)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+    for k, v in m.state_dict().items():
+        d["small/sd0/" + k] = npy(v.clone())       # clone: the forward updates the BN buffers in place
+    x = torch.randn(3, 2, 8, 4, 12, generator=g)
+    y = torch.randint(0, 3, (3, 1, 8, 4, 12), generator=g)
+    m.train()
+    handles, store = _record_dropout_masks(m, torch.nn.Dropout3d)
+    torch.manual_seed(99)
+    logits = m(x)
+    loss = ref_metrics.combined_loss(logits, y)
+    loss.backward()
+    for h in handles:
+        h.remove()
+    d["small/x"], d["small/y"], d["small/logits"], d["small/loss"] = npy(x), npy(y), npy(logits), npy(loss)
+    for name, lst in store.items():
+        d["small/mask/" + name] = npy(lst[0])
+    for k, p in m.named_parameters():
+        d["small/grad/" + k] = npy(p.grad)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            d["small/sd1/" + k] = npy(v)
+    # default net, N=2, 16^3, p=0.1 (the _ct_ scripts' setting): summary
+    torch.manual_seed(0)
+    m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.1)
+    m.train()
+    x, y = synth(2, 16, 1234)
+    handles, store = _record_dropout_masks(m, torch.nn.Dropout3d)
+    torch.manual_seed(5)
+    logits = m(x)
+    loss = ref_metrics.combined_loss(logits, y)
+    loss.backward()
+    for h in handles:
+        h.remove()
+    for name, lst in store.items():
+        d["default/mask/" + name] = npy(lst[0])
+    d["default/logits"], d["default/loss"] = npy(logits), npy(loss)
+    _summ(d, "default/", m)
+    np.savez_compressed(os.path.join(out, "dropout.npz"), **d)
+
+
+def _autocast_yardstick(d, pre, ref_unet, ref_metrics, x, y, fp32_logits, fp32_grads, seed=0):
+    """The reference's own bf16 autocast run (accelerate mixed_precision='bf16') vs its fp32 run on the same inputs."""
+    torch.manual_seed(seed)
+    m2 = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    m2.train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        lg2 = m2(x)
+    lg2 = lg2.float()
+    loss2 = ref_metrics.combined_loss(lg2, y)
+    loss2.backward()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    d[pre + "logits_relerr"] = np.asarray(rel(lg2.detach(), fp32_logits))
+    d[pre + "loss"] = npy(loss2)
+    d[pre + "dice"] = npy(ref_metrics.calculate_dice(lg2, y))
+    d[pre + "iou"] = npy(ref_metrics.calculate_iou(lg2, y))
+    d[pre + "acc"] = npy(ref_metrics.calculate_accuracy(lg2, y))
+    d[pre + "grad_relerr"] = np.array([rel(p.grad, fp32_grads[k]) for k, p in m2.named_parameters()])
+
+
+def gen_config2(ref_unet, ref_metrics, out):
+    """BASELINE config 2 at its real size: UNet3D 96^3, N=2 (fp32 reference + the reference's autocast-bf16 run)."""
+    d = {}
+    torch.manual_seed(0)
+    m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    x, y = synth(2, 96, 1234)
+    m.train()
+    logits = m(x)
+    loss = ref_metrics.combined_loss(logits, y)
+    loss.backward()
+    d["loss"] = npy(loss)
+    d["dice"], d["iou"], d["acc"] = (npy(ref_metrics.calculate_dice(logits, y)), npy(ref_metrics.calculate_iou(logits, y)),
+                                     npy(ref_metrics.calculate_accuracy(logits, y)))
+    _summ(d, "", m, logits.detach())
+    fp32_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    _autocast_yardstick(d, "autocast_bf16/", ref_unet, ref_metrics, x, y, logits.detach(), fp32_grads)
+    np.savez_compressed(os.path.join(out, "config2_96.npz"), **d)
+
+
+def gen_config5(ref_unet, ref_metrics, out):
+    """BASELINE config 5: distillation step (distill_unet.py:107-115) at 128^3, N=2, alpha 0.7, T 2.0."""
+    d = {}
+    torch.manual_seed(0)
+    student = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    torch.manual_seed(1)
+    teacher = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, b in teacher.named_buffers():
+            if k.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            if k.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    student.train(); teacher.eval()
+    x, y = synth(2, 128, 1234)
+    s = student(x)
+    with torch.no_grad():
+        t = teacher(x)
+    l = ref_metrics.distillation_loss(s, t, y, 0.7, 2.0)
+    l.backward()
+    d["loss"] = npy(l)
+    d["dice"] = npy(ref_metrics.calculate_dice(s, y))
+    _summ(d, "student/", student, s.detach())
+    tt = {}
+    _summ_logits = {}
+    a, b = 62, 66
+    d["teacher/logits_center"] = npy(t[:, :, a:b, a:b, a:b])
+    d["teacher/logits_absmean"] = np.asarray(float(t.double().abs().mean()))
+    d["teacher/logits_mean_per_class"] = npy(t.double().mean(dim=(0, 2, 3, 4)))
+    np.savez_compressed(os.path.join(out, "config5_128.npz"), **d)
+
+
+def _ct_like(x):
+    """images in HU-like units pushed through the reference's CT window (utils/dataloader.py:111-117)"""
+    hu = 200.0 * x.numpy()
+    hu = np.clip(hu, -160, 240)
+    return torch.from_numpy(((hu - (-160)) / (240 - (-160))).astype(np.float32))
+
+
+def _mri_like(x):
+    """utils/dataloader.py:128-144 on each volume: z-score, 1-99 percentile clip, min-max"""
+    outs = []
+    for v in x.numpy():
+        im = (v - np.mean(v)) / (np.std(v) + 1e-8)
+        low, high = np.percentile(im, [1, 99])
+        im = np.clip(im, low, high)
+        outs.append(((im - low) / (high - low + 1e-8)).astype(np.float32))
+    return torch.from_numpy(np.stack(outs))
+
+
+class _Args:
+    pass
+
+
+def gen_config4(ref_unet_dann, ref_train_unet, ref_train_dann, out):
+    """BASELINE config 4 per rank: the reference's own train_one_epoch_dann (train_dann.py:225-301) on ONE batch of
+    N=2 source (CT-like, labelled) + N=2 target (MRI-like) 96^3 volumes, lambda 0.2, loss ce_tversky (its default),
+    AdamW lr 1e-3 wd 0.01 for both nets (train_dann.py:421-422), Dropout masks of the discriminator recorded."""
+    d = {}
+    torch.manual_seed(0)
+    seg = ref_unet_dann.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    torch.manual_seed(3)
+    disc = ref_train_dann.DomainDiscriminator(256)
+    xs, ys = synth(2, 96, 1234)
+    xt, _ = synth(2, 96, 4321)
+    xs, xt = _ct_like(xs), _mri_like(xt)
+    opt_s = torch.optim.AdamW(seg.parameters(), lr=1e-3, weight_decay=0.01)
+    opt_d = torch.optim.AdamW(disc.parameters(), lr=1e-3, weight_decay=0.01)
+    args = _Args()
+    args.epochs, args.gradient_accumulation_steps = 1, 1
+    handles, store = _record_dropout_masks(disc, torch.nn.Dropout)
+    feats = []
+    h2 = disc.register_forward_hook(lambda mod, inp, outp: feats.append((inp[0].detach().clone(), outp.detach().clone())))
+    torch.manual_seed(77)
+    res = ref_train_dann.train_one_epoch_dann(seg, disc, ([(xs, ys)], [(xt, torch.zeros(1))]), opt_s, opt_d,
+                                              torch.device("cpu"), 0, args, ref_train_unet.get_loss_fn("ce_tversky"), 0.2)
+    for h in handles + [h2]:
+        h.remove()
+    d["task"], d["domain"], d["dice"], d["iou"], d["acc"] = [np.asarray(float(v)) for v in res]
+    d["xs_stats"] = np.array([float(xs.mean()), float(xs.std()), float(xt.mean()), float(xt.std())])
+    d["sfeat"], d["tfeat"] = npy(feats[0][0]), npy(feats[1][0])
+    d["spred"], d["tpred"] = npy(feats[0][1]), npy(feats[1][1])
+    for name, lst in store.items():
+        d["disc_mask/" + name] = np.stack([npy(v) for v in lst])       # [2 calls (source, target)][N][features]
+    _summ(d, "seg/", seg)
+    d["disc/grad_names"] = np.array([k for k, _ in disc.named_parameters()])
+    d["disc/grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in disc.named_parameters()])
+    for k, p in disc.named_parameters():
+        d["disc/grad/" + k] = npy(p.grad if p.numel() <= 4096 else p.grad[:4])
+    _, dig = param_digest(seg.state_dict())
+    d["seg/param_digest_after"] = dig
+    _, dig = param_digest(disc.state_dict())
+    d["disc/param_digest_after"] = dig
+    np.savez_compressed(os.path.join(out, "config4_dann96.npz"), **d)
+
+
+def gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, out):
+    """The reference's step loops executed as they are, at 16^3:
+      accum/   train_unet.train_one_epoch (train_unet.py:207-257) under Accelerator(gradient_accumulation_steps=2): 4
+               micro-batches = 2 optimizer steps.  Pins Q2 (zero_grad inside accumulate(): only the boundary
+               micro-batch's gradient survives, scaled 1/accum).
+      eval/    train_unet.evaluate (:259-305) with the ce_tversky loss on 2 batches of 1.
+      dann/    train_dann.train_one_epoch_dann with gradient_accumulation_steps=2 over 2 batches (one optimizer step)."""
+    import tempfile
+    from accelerate import Accelerator
+    d = {}
+    tmp = tempfile.mkdtemp()
+    args = _Args()
+    args.epochs, args.experiment_dir, args.experiment_name = 1, tmp, "x"
+    os.makedirs(os.path.join(tmp, "x", "logs"), exist_ok=True)
+    acc = Accelerator(gradient_accumulation_steps=2, cpu=True)
+    torch.manual_seed(0)
+    m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+    m, opt = acc.prepare(m, opt)
+    loader = [synth(2, 16, 500 + i, blocky=(i % 2 == 0)) for i in range(4)]
+    loss_fn = ref_train_unet.get_loss_fn("combined")
+    res = ref_train_unet.train_one_epoch(m, loader, opt, acc, 0, args, loss_fn)
+    d["accum/result"] = np.array([float(v) for v in res])
+    mm = acc.unwrap_model(m)
+    _summ(d, "accum/", mm)
+    _, dig = param_digest(mm.state_dict())
+    d["accum/param_digest_after"] = dig
+    # evaluate() on the model as trained above, ce_tversky loss
+    ev_loader = [synth(1, 16, 600 + i, blocky=True) for i in range(2)]
+    res = ref_train_unet.evaluate(m, ev_loader, acc, 0, args, ref_train_unet.get_loss_fn("ce_tversky"))
+    d["eval/result"] = np.array([float(v) for v in res])
+    per = []
+    mm.eval()
+    with torch.no_grad():
+        for xx, yy in ev_loader:
+            per.append(float(ref_train_unet.get_loss_fn("ce_tversky")(mm(xx), yy)))
+    d["eval/per_batch_loss"] = np.array(per)
+    # DANN loop with accumulation 2 (train_dann.py:237-239,286-289): both micro-batches accumulate, one step
+    torch.manual_seed(0)
+    seg = ref_unet_dann.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    torch.manual_seed(3)
+    disc = ref_train_dann.DomainDiscriminator(256)
+    for mod in disc.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    opt_s = torch.optim.AdamW(seg.parameters(), lr=1e-3, weight_decay=0.01)
+    opt_d = torch.optim.AdamW(disc.parameters(), lr=1e-3, weight_decay=0.01)
+    a2 = _Args()
+    a2.epochs, a2.gradient_accumulation_steps = 1, 2
+    src = [synth(2, 16, 700 + i) for i in range(2)]
+    tgt = [(synth(2, 16, 800 + i)[0], torch.zeros(1)) for i in range(2)]
+    res = ref_train_dann.train_one_epoch_dann(seg, disc, (src, tgt), opt_s, opt_d, torch.device("cpu"), 0, a2,
+                                              ref_train_unet.get_loss_fn("combined"), 0.2)
+    d["dann/result"] = np.array([float(v) for v in res])      # task, domain, dice, iou, acc (means over the 2 batches)
+    _summ(d, "dann/seg/", seg)
+    d["dann/disc_grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in disc.named_parameters()])
+    _, dig = param_digest(seg.state_dict())
+    d["dann/seg_param_digest_after"] = dig
+    _, dig = param_digest(disc.state_dict())
+    d["dann/disc_param_digest_after"] = dig
+    np.savez_compressed(os.path.join(out, "loops.npz"), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma-separated fixture names (default: all)")
     a = ap.parse_args()
+    only = set(filter(None, a.only.split(",")))
+    want = lambda name: not only or name in only
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
     torch.use_deterministic_algorithms(False)
     ref_unet, ref_unet_dann, ref_metrics, ref_train_unet, ref_train_dann = _import_reference()
-    gen_small_unet(ref_unet, ref_metrics, a.out)
-    gen_doubleconv(ref_unet, a.out)
-    gen_losses(ref_metrics, ref_train_unet, a.out)
-    gen_default_unet(ref_unet, ref_metrics, a.out)
-    gen_dann(ref_unet_dann, ref_metrics, ref_train_dann, a.out)
-    gen_distill(ref_unet, ref_metrics, a.out)
+    if want("small_unet"): gen_small_unet(ref_unet, ref_metrics, a.out)
+    if want("doubleconv"): gen_doubleconv(ref_unet, a.out)
+    if want("losses_metrics"): gen_losses(ref_metrics, ref_train_unet, a.out)
+    if want("default_unet"): gen_default_unet(ref_unet, ref_metrics, a.out)
+    if want("dann"): gen_dann(ref_unet_dann, ref_metrics, ref_train_dann, a.out)
+    if want("distill"): gen_distill(ref_unet, ref_metrics, a.out)
+    if want("dropout"): gen_dropout(ref_unet, ref_metrics, a.out)
+    if want("loops"): gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
+    if want("config2_96"): gen_config2(ref_unet, ref_metrics, a.out)
+    if want("config4_dann96"): gen_config4(ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
+    if want("config5_128"): gen_config5(ref_unet, ref_metrics, a.out)
     with open(os.path.join(a.out, "PROVENANCE.txt"), "w") as f:
         f.write("generated by tools/gen_golden.py from /root/reference (fransiskusbudi/multimodal_segmentation_project @ 2025-08-24)\n")
         f.write(f"torch {torch.__version__} CPU, numpy {np.__version__}, threads {torch.get_num_threads()}\n")
