@@ -154,7 +154,7 @@ def main():
     model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=a.dropout).to(dev).train()
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt,
-                   use_graph=(world == 1 and not a.no_graph), two_stream=a.two_stream)
+                   use_graph=not a.no_graph, two_stream=a.two_stream)
     x, y = synth(a.batch, a.size, 1234 + rank)
     ts.load_batch(x.to(dev), y.to(dev))
 

@@ -39,7 +39,8 @@ def adamw_state_dict(train_step):
         n = p.numel()
         state[i] = {"step": step.clone(), "exp_avg": a.m[o:o + n].view(p.shape).detach().cpu().clone(),
                     "exp_avg_sq": a.v[o:o + n].view(p.shape).detach().cpu().clone()}
-    group = {"lr": train_step.lr, "betas": tuple(train_step.betas), "eps": train_step.eps, "weight_decay": train_step.wd,
+    lr, b1, b2, eps, wd = train_step._hyper()[:5]
+    group = {"lr": lr, "betas": (b1, b2), "eps": eps, "weight_decay": wd,
              "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
              "fused": None, "decoupled_weight_decay": True, "params": list(range(len(a.params)))}
     return {"state": state, "param_groups": [group]}

@@ -189,6 +189,7 @@ class _StepBase:
         return (self.micro % self.accum == 0, (self.micro + 1) % self.accum == 0)
 
     def _run(self, st):
+        self._check_mode()
         variant = self._variant()
         if not self.use_graph:
             self._enqueue(st, variant, lambda fn: fn())
@@ -384,15 +385,17 @@ class TrainStep(_StepBase):
         self._statics[key] = st
         return st
 
+    def _check_mode(self):
+        if not self.model.training:
+            raise Mi3dError("TrainStep.step() on a model in eval mode: the backward kernels use batch statistics "
+                            "(train_unet.py:208 calls model.train() first); use evaluate() for eval-mode passes")
+
     # ---- the kernel sequence of one micro-step (everything on the current stream except the all-reduces)
     def _enqueue(self, st, variant, comm):
         first, boundary = variant
         desc = st["desc"]
         s = stream_ptr()
         model = self.model
-        if not model.training:
-            raise Mi3dError("TrainStep.step() on a model in eval mode: the backward kernels use batch statistics "
-                            "(train_unet.py:208 calls model.train() first); use evaluate() for eval-mode passes")
         # Q2: see reference_zero_grad_quirk in __init__
         if self.quirk:
             accumulate, run_backward = 0, boundary
@@ -541,6 +544,10 @@ class DannStep(_StepBase):
             self.disc._mi3d_rng_state = st
         return st
 
+    def _check_mode(self):
+        if not self.model.training or not self.disc.training:
+            raise Mi3dError("DannStep.step() needs both models in train mode (train_dann.py:226-227)")
+
     def _prepare(self, xs, xt):
         if tuple(xs.shape) != tuple(xt.shape):
             raise Mi3dError(f"source batch {tuple(xs.shape)} and target batch {tuple(xt.shape)} must have one shape "
@@ -602,8 +609,6 @@ class DannStep(_StepBase):
         desc, L = st["desc"], st["L"]
         s = stream_ptr()
         seg, disc = self.model, self.disc
-        if not seg.training or not disc.training:
-            raise Mi3dError("DannStep.step() needs both models in train mode (train_dann.py:226-227)")
         accumulate = 0 if first else 1
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
         lam = self.lam
@@ -716,6 +721,7 @@ class DannStep(_StepBase):
             first = self.micro % self.accum == 0
             if self.use_graph:
                 raise Mi3dError("last_batch with a partial accumulation window is not graph-captured; use use_graph=False")
+            self._check_mode()
             self._enqueue(st, (first, True), lambda fn: fn())
             self.micro += self.accum - (self.micro % self.accum)
         else:

@@ -349,3 +349,168 @@ def test_learnable_run_converges(dtype):
     assert float(last[2]) > 0.9, last                                   # train-mode Dice
     ev = ts.evaluate(x, y).cpu()
     assert float(ev[2]) > 0.9, ev                                       # eval mode: BN running statistics are usable
+
+
+def _nccl1_worker(port, q):
+    """1-rank RCCL group on the 1-GPU box: the bucket path (side stream, ReduceOp.AVG all-reduces, joins, segmented step
+    graphs) runs for real and must be bitwise invisible."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import multimodal_segmentation_project_amd as mi
+        from multimodal_segmentation_project_amd import unet_dann
+        from multimodal_segmentation_project_amd.dann import DomainDiscriminator
+        from multimodal_segmentation_project_amd.trainer import DannStep, TrainStep
+        dev = torch.device("cuda", 0)
+        x, y = _synth(2, 32, 77)
+        xt, _ = _synth(2, 32, 78)
+        outs = {}
+        for name, kw in (("plain", {}), ("comm_eager", dict(force_comm=True)), ("comm_graph", dict(force_comm=True, use_graph=True)),
+                         ("graph", dict(use_graph=True))):
+            torch.manual_seed(0)
+            model = mi.UNet3D(1, 4, dropout_rate=0.1).to(dev).train()
+            ts = TrainStep(model, lr=1e-3, weight_decay=0.01, compute_dtype=torch.bfloat16, **kw)
+            assert ts.do_comm == ("comm" in name)
+            ts.load_batch(x.to(dev), y.to(dev))
+            mets = [ts.step_static().clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            nseg = len(next(iter(ts._static["graphs"].by_variant.values()))) if ts.use_graph else 0
+            ts.sync_buffers()
+            outs[name] = (torch.stack(mets).cpu(), ts.arena.p.clone().cpu(), nseg)
+        base = outs["plain"]
+        for name, o in outs.items():
+            assert torch.equal(o[0], base[0]) and torch.equal(o[1], base[1]), name
+        assert outs["graph"][2] == 1 and outs["comm_graph"][2] >= 6          # comm-free runs of kernels between all-reduces
+        # DANN under forced communication (discriminator arena = the fifth bucket)
+        douts = []
+        for kw in ({}, dict(force_comm=True, use_graph=True)):
+            torch.manual_seed(0)
+            seg = unet_dann.UNet3D(1, 4, dropout_rate=0.0).to(dev).train()
+            torch.manual_seed(3)
+            disc = DomainDiscriminator(256).to(dev).train()
+            st = DannStep(seg, disc, loss="ce_tversky", lambda_domain=0.2, compute_dtype=torch.bfloat16, **kw)
+            st.load_batch(x.to(dev), y.to(dev), xt.to(dev))
+            mets = [st.step_static().clone() for _ in range(2)]
+            torch.cuda.synchronize()
+            douts.append((torch.stack(mets).cpu(), st.arena.p.clone().cpu(), st.disc_arena.p.clone().cpu()))
+        for a, b in zip(*douts):
+            assert torch.equal(a, b)
+        q.put("ok")
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put("err " + repr(e) + traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_forced_comm_path_over_rccl_is_bitwise_invisible():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert res == "ok", res
+
+
+def _dp2_modes_worker(rank, world, port, q):
+    """world 2 over gloo on one GPU: gradient accumulation + DP, frozen encoder + DP, DANN + DP, segmented graphs."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import multimodal_segmentation_project_amd as mi
+        from multimodal_segmentation_project_amd import unet_dann
+        from multimodal_segmentation_project_amd.dann import DomainDiscriminator
+        from multimodal_segmentation_project_amd.trainer import DannStep, TrainStep
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        res = {}
+        # (a) accumulation 2 under DP with segmented graphs: gradients are exchanged on the boundary micro-step only
+        torch.manual_seed(50 + rank)
+        model = mi.UNet3D(1, 4, dropout_rate=0.0).to(dev).train()
+        ts = TrainStep(model, lr=1e-3, weight_decay=0.01, compute_dtype=torch.float32, grad_accum=2, use_graph=True)
+        for i in range(2):
+            x, y = _synth(1, 32, 900 + 10 * i + rank)
+            met = ts.step(x.to(dev), y.to(dev)).clone()
+        torch.cuda.synchronize()
+        res["accum_g"], res["accum_p"], res["accum_met"] = ts.arena.g.cpu().numpy(), ts.arena.p.cpu().numpy(), met.cpu().numpy()
+        # (b) frozen encoder + bottleneck under DP
+        torch.manual_seed(60 + rank)
+        model = mi.UNet3D(1, 4, dropout_rate=0.0).to(dev).train()
+        for mod in (model.encoder, model.bottleneck):
+            for p in mod.parameters():
+                p.requires_grad = False
+        ts = TrainStep(model, lr=1e-3, weight_decay=0.01, compute_dtype=torch.float32)
+        x, y = _synth(1, 32, 950 + rank)
+        ts.step(x.to(dev), y.to(dev))
+        torch.cuda.synchronize()
+        res["frz_g"], res["frz_p"] = ts.arena.g.cpu().numpy(), ts.arena.p.cpu().numpy()
+        res["frz_sched"] = sorted(ts._static["comm_after"].items())
+        # (c) DANN under DP
+        torch.manual_seed(70 + rank)
+        seg = unet_dann.UNet3D(1, 4, dropout_rate=0.0).to(dev).train()
+        torch.manual_seed(80 + rank)
+        disc = DomainDiscriminator(256).to(dev).train()
+        st = DannStep(seg, disc, loss="combined", lambda_domain=0.2, lr=1e-3, weight_decay=0.01, compute_dtype=torch.float32)
+        st.disc_p = [0.0, 0.0]
+        xs, ys = _synth(2, 16, 700 + rank)
+        xt, _ = _synth(2, 16, 800 + rank)
+        p0, d0 = st.arena.p.clone(), st.disc_arena.p.clone()
+        met = st.step(xs.to(dev), ys.to(dev), xt.to(dev)).clone()
+        torch.cuda.synchronize()
+        res["dann_p0"], res["dann_d0"] = p0.cpu().numpy(), d0.cpu().numpy()
+        res["dann_g"], res["dann_dg"] = st.arena.g.cpu().numpy(), st.disc_arena.g.cpu().numpy()
+        res["dann_met"] = met.cpu().numpy()
+        q.put((rank, "ok", res))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put((rank, "err " + repr(e) + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_accumulation_frozen_and_dann():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp2_modes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    a, b = res[0][2], res[1][2]
+    for k in ("accum_g", "accum_p", "frz_g", "frz_p", "dann_g", "dann_dg", "dann_p0", "dann_d0"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)          # identical on both ranks after the exchange
+    np.testing.assert_allclose(a["accum_met"], b["accum_met"])
+    np.testing.assert_allclose(a["dann_met"], b["dann_met"])
+    # frozen encoder: only the decoder bucket is exchanged (after the last run segment)
+    assert len(a["frz_sched"]) == 1
+    # DANN reference: single-process DannStep on each rank's shard from the broadcast parameters, gradients averaged
+    import multimodal_segmentation_project_amd as mi
+    from multimodal_segmentation_project_amd import unet_dann
+    from multimodal_segmentation_project_amd.dann import DomainDiscriminator
+    from multimodal_segmentation_project_amd.trainer import DannStep
+    dev = "cuda:0"
+    gs, dgs, mets = [], [], []
+    for r in range(2):
+        seg = unet_dann.UNet3D(1, 4, dropout_rate=0.0).to(dev).train()
+        disc = DomainDiscriminator(256).to(dev).train()
+        st = DannStep(seg, disc, loss="combined", lambda_domain=0.2, lr=0.0, weight_decay=0.0, compute_dtype=torch.float32)
+        st.disc_p = [0.0, 0.0]
+        st.arena.p.copy_(torch.from_numpy(a["dann_p0"]))
+        st.disc_arena.p.copy_(torch.from_numpy(a["dann_d0"]))
+        xs, ys = _synth(2, 16, 700 + r)
+        xt, _ = _synth(2, 16, 800 + r)
+        mets.append(st.step(xs.to(dev), ys.to(dev), xt.to(dev)).cpu().numpy().copy())
+        gs.append(st.arena.g.cpu().numpy().copy())
+        dgs.append(st.disc_arena.g.cpu().numpy().copy())
+    ref, dref = 0.5 * (gs[0] + gs[1]), 0.5 * (dgs[0] + dgs[1])
+    assert np.linalg.norm(a["dann_g"] - ref) / np.linalg.norm(ref) < 1e-5
+    assert np.linalg.norm(a["dann_dg"] - dref) / np.linalg.norm(dref) < 1e-5
+    np.testing.assert_allclose(a["dann_met"], 0.5 * (mets[0] + mets[1]), rtol=1e-5)

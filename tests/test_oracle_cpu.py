@@ -251,7 +251,7 @@ def test_oracle_loop_reproduces_reference_accumulation_quirk(golden):
             x = y.float() / 3.0 + 0.1 * x
         return x, y
 
-    batches = [synth(2, 16, 500 + i, i % 2 == 0) for i in range(4)]
+    batches = [synth(2, 32, 500 + i, i % 2 == 0) for i in range(4)]
     torch.manual_seed(0)
     sd0 = {k: v.detach().clone() for k, v in mi.UNet3D(1, 4, dropout_rate=0.0).state_dict().items()}
     sd_q, losses, grads = torch_ref.train_loop(sd0, batches, accum=2, zero_grad_quirk=True)

@@ -622,7 +622,8 @@ def gen_config4(ref_unet_dann, ref_train_unet, ref_train_dann, out):
 
 
 def gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, out):
-    """The reference's step loops executed as they are, at 16^3:
+    """The reference's step loops executed as they are, at 32^3 (a 16^3 input has a 1x1x1 bottleneck whose
+    BatchNorm over 2 values amplifies fp32 roundoff):
       accum/   train_unet.train_one_epoch (train_unet.py:207-257) under Accelerator(gradient_accumulation_steps=2): 4
                micro-batches = 2 optimizer steps.  Pins Q2 (zero_grad inside accumulate(): only the boundary
                micro-batch's gradient survives, scaled 1/accum).
@@ -640,7 +641,7 @@ def gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, out):
     m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
     m, opt = acc.prepare(m, opt)
-    loader = [synth(2, 16, 500 + i, blocky=(i % 2 == 0)) for i in range(4)]
+    loader = [synth(2, 32, 500 + i, blocky=(i % 2 == 0)) for i in range(4)]
     loss_fn = ref_train_unet.get_loss_fn("combined")
     res = ref_train_unet.train_one_epoch(m, loader, opt, acc, 0, args, loss_fn)
     d["accum/result"] = np.array([float(v) for v in res])
@@ -648,8 +649,18 @@ def gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, out):
     _summ(d, "accum/", mm)
     _, dig = param_digest(mm.state_dict())
     d["accum/param_digest_after"] = dig
+    # the same loop stopped after the FIRST accumulation window (2 micro-batches, one optimizer step): its gradients are
+    # grad(second micro-batch)/2 at the initial parameters -- free of AdamW's sign-like nonlinearity
+    acc1 = Accelerator(gradient_accumulation_steps=2, cpu=True)
+    torch.manual_seed(0)
+    m1 = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    opt1 = torch.optim.AdamW(m1.parameters(), lr=1e-3, weight_decay=0.01)
+    m1, opt1 = acc1.prepare(m1, opt1)
+    res1 = ref_train_unet.train_one_epoch(m1, loader[:2], opt1, acc1, 0, args, loss_fn)
+    d["accum_first/result"] = np.array([float(v) for v in res1])
+    _summ(d, "accum_first/", acc1.unwrap_model(m1))
     # evaluate() on the model as trained above, ce_tversky loss
-    ev_loader = [synth(1, 16, 600 + i, blocky=True) for i in range(2)]
+    ev_loader = [synth(1, 32, 600 + i, blocky=True) for i in range(2)]
     res = ref_train_unet.evaluate(m, ev_loader, acc, 0, args, ref_train_unet.get_loss_fn("ce_tversky"))
     d["eval/result"] = np.array([float(v) for v in res])
     per = []
@@ -670,8 +681,8 @@ def gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, out):
     opt_d = torch.optim.AdamW(disc.parameters(), lr=1e-3, weight_decay=0.01)
     a2 = _Args()
     a2.epochs, a2.gradient_accumulation_steps = 1, 2
-    src = [synth(2, 16, 700 + i) for i in range(2)]
-    tgt = [(synth(2, 16, 800 + i)[0], torch.zeros(1)) for i in range(2)]
+    src = [synth(2, 32, 700 + i) for i in range(2)]
+    tgt = [(synth(2, 32, 800 + i)[0], torch.zeros(1)) for i in range(2)]
     res = ref_train_dann.train_one_epoch_dann(seg, disc, (src, tgt), opt_s, opt_d, torch.device("cpu"), 0, a2,
                                               ref_train_unet.get_loss_fn("combined"), 0.2)
     d["dann/result"] = np.array([float(v) for v in res])      # task, domain, dice, iou, acc (means over the 2 batches)
