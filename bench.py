@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3 --pmc passes)")
+    ap.add_argument("--workload", default="train", choices=["train", "distill", "dann", "eval"],
+                    help="train = the headline metric (BASELINE config 2/3); distill = config 5 step (student + frozen teacher); "
+                         "dann = config 4 step (N source + N target volumes per GPU); eval = inference forward + loss + metrics")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,12 +154,31 @@ def main():
         print(json.dumps(roofline_dominant(a.size, a.batch, 1 if a.dtype == "bf16" else 0, iters=a.steps)))
         return
     torch.manual_seed(0)
-    model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=a.dropout).to(dev).train()
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt,
-                   use_graph=not a.no_graph, two_stream=a.two_stream)
     x, y = synth(a.batch, a.size, 1234 + rank)
-    ts.load_batch(x.to(dev), y.to(dev))
+    if a.workload == "dann":
+        from multimodal_segmentation_project_amd import unet_dann
+        from multimodal_segmentation_project_amd.dann import DomainDiscriminator
+        from multimodal_segmentation_project_amd.trainer import DannStep
+        model = unet_dann.UNet3D(in_channels=1, out_channels=4, dropout_rate=a.dropout).to(dev).train()
+        torch.manual_seed(3)
+        disc = DomainDiscriminator(256).to(dev).train()
+        ts = DannStep(model, disc, loss="ce_tversky", lambda_domain=0.2, lr=1e-3, weight_decay=0.01, compute_dtype=cdt,
+                      use_graph=not a.no_graph)
+        xt, _ = synth(a.batch, a.size, 4321 + rank)
+        ts.load_batch(x.clamp(0, 1).to(dev), y.to(dev), ((xt - xt.min()) / (xt.max() - xt.min())).to(dev))
+    else:
+        model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=a.dropout).to(dev).train()
+        teacher = None
+        if a.workload == "distill":
+            torch.manual_seed(1)
+            teacher = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).eval()
+        ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt, kd_teacher=teacher,
+                       use_graph=not a.no_graph, two_stream=a.two_stream)
+        ts.load_batch(x.to(dev), y.to(dev))
+    if a.workload == "eval":
+        xd, yd = x.to(dev), y.to(dev)
+        ts.step_static = lambda: ts.evaluate(xd, yd)
 
     for _ in range(a.warmup):
         ts.step_static()
@@ -186,8 +208,9 @@ def main():
             "metric": "3D volumes/sec (96^3, 4-class) fwd+bwd per node", "value": value, "unit": "volumes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"UNet3D(1->4, features 16/32/64/128) {a.size}^3 patch, per-GPU batch {a.batch}, "
-                                   f"fwd + Dice/CE loss + bwd + AdamW + metrics, dropout {a.dropout}",
+            "config": {"workload": (f"UNet3D(1->4, features 16/32/64/128) {a.size}^3 patch, per-GPU batch {a.batch}, "
+                                    f"fwd + Dice/CE loss + bwd + AdamW + metrics, dropout {a.dropout}") if a.workload == "train"
+                       else f"{a.workload} step, UNet3D {a.size}^3, per-GPU batch {a.batch}",
                        "global_batch": global_batch, "parallelism": f"dp{world}", "hipgraph": bool(ts.use_graph)},
             "final_step": {"loss": met[0], "iou": met[1], "dice": met[2], "acc": met[3]},
             "step_hbm_frac": algo_gb_step / (ms * 1e-3) / HBM_PEAK_GBS,

@@ -71,6 +71,15 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
                       const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Inference forward (eval mode, no backward possible afterwards).  Replaces model.eval() + forward of
+ * train_unet.py:259-305 (evaluate), test_model.py:242-251 and the frozen teacher of distill_unet.py:109-111,216-220:
+ * eval-mode BatchNorm3d is folded into the preceding Conv3d (filter * gamma/sqrt(running_var+eps) at pack time, bias
+ * replaced), ReLU runs in the conv epilogue, Dropout3d is the identity, and each conv writes the activated tensor
+ * directly -- no raw conv outputs, statistics or saved activations.  Same workspace size as mi3d_unet_forward; buffers
+ * (running statistics) are read-only here. */
+int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers, float* logits,
+                    float* gap_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of the last mi3d_unet_forward on this workspace.  dlogits (N,out,D,H,W) float or NULL (target pass of
  * DANN: only the GAP branch carries gradient, train_dann.py:271-285); dgap (N,2*features[L-1]) float or NULL, its
  * contribution is scaled by gap_scale (gradient reversal folds in as gap_scale = -lambda, train_dann.py:29).

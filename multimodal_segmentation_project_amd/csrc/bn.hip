@@ -296,6 +296,16 @@ __global__ __launch_bounds__(BLK) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// inference: every BatchNorm of the network folded into its conv in one launch (block = one layer)
+__global__ void bn_fold_all_kernel(BnFoldJobs J) {
+    const BnFoldJob& j = J.j[blockIdx.x];
+    for (int c = threadIdx.x; c < j.C; c += blockDim.x) {
+        double a = (double)j.gamma[c] / sqrt((double)j.rv[c] + (double)J.eps);
+        j.scale[c] = (float)a;
+        j.fbias[c] = (float)(((double)(j.conv_bias ? j.conv_bias[c] : 0.f) - (double)j.rm[c]) * a + (double)j.beta[c]);
+    }
+}
+
 inline bool vec8_ok(int C, int cs_a, int cs_b, const void* pa, const void* pb, int esz) {
     return C % 8 == 0 && cs_a % 8 == 0 && cs_b % 8 == 0 && ((uintptr_t)pa % 16 == 0) && ((uintptr_t)pb % 16 == 0) &&
            (C / 8) <= BLK && esz > 0;
@@ -413,6 +423,13 @@ int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, 
     bn_stats_splitk_kernel<<<nblk, BLK, lds, s>>>(skp, ks, bias, (bf16*)y, ycs, C, M, ws);
     MI3D_LAUNCH_CHECK();
     bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_fold_all(const BnFoldJobs& J, hipStream_t s) {
+    MI3D_CHECK_ARG(J.n >= 1 && J.n <= MAX_FOLD_JOBS, "bn_fold_all: bad job count %d", J.n);
+    bn_fold_all_kernel<<<J.n, 256, 0, s>>>(J);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -25,7 +25,7 @@ constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
 constexpr int COT = 16;                        // output channels per thread
 
 __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ wf,
-                            float* __restrict__ wd) {
+                            float* __restrict__ wd, const float* __restrict__ scale) {
     // wf[((cb*Cin + ci)*27 + tap)*16 + j] = w[cb*16+j][ci][tap]
     // wd[((cb*Cout + co)*27 + tap)*16 + j] = w[co][cb*16+j][26-tap]
     int64_t nf = (int64_t)cdiv(Cout, COT) * COT * Cin * 27, nd = (int64_t)cdiv(Cin, COT) * COT * Cout * 27;
@@ -33,7 +33,7 @@ __global__ void pack_kernel(const float* __restrict__ w, int Cin, int Cout, floa
         if (i < nf) {
             int j = i % COT; int64_t r = i / COT; int tap = r % 27; r /= 27; int ci = r % Cin; int cb = r / Cin;
             int co = cb * COT + j;
-            if (wf) wf[i] = co < Cout ? w[((int64_t)co * Cin + ci) * 27 + tap] : 0.f;
+            if (wf) wf[i] = co < Cout ? w[((int64_t)co * Cin + ci) * 27 + tap] * (scale ? scale[co] : 1.f) : 0.f;
         } else {
             int64_t k = i - nf;
             int j = k % COT; int64_t r = k / COT; int tap = r % 27; r /= 27; int co = r % Cout; int cb = r / Cout;
@@ -82,7 +82,7 @@ template <typename TI, typename TO, int CIC>
 __global__ __launch_bounds__(BLK) void conv3_direct_kernel(const TI* __restrict__ x, int xcs, int Cin,
                                                            const float* __restrict__ wp, const float* __restrict__ bias,
                                                            TO* __restrict__ y, int ycs, int Cout, int D, int H, int W,
-                                                           int tilesZ, int tilesY, int tilesX) {
+                                                           int tilesZ, int tilesY, int tilesX, int relu) {
     constexpr int STR = (CIC == 8) ? 12 : 1;   // LDS voxel stride (floats); 12 keeps b128 reads 16-B aligned
     __shared__ __attribute__((aligned(16))) float xs[IZ * IY * IX * STR];
     int tile = blockIdx.x;
@@ -133,6 +133,10 @@ __global__ __launch_bounds__(BLK) void conv3_direct_kernel(const TI* __restrict_
         if (bias) {
 #pragma unroll
             for (int j = 0; j < COT; j++) if (co0 + j < Cout) acc[j] += bias[co0 + j];
+        }
+        if (relu) {                   // inference: BatchNorm folded into (weights, bias), ReLU here
+#pragma unroll
+            for (int j = 0; j < COT; j++) acc[j] = fmaxf(acc[j], 0.f);
         }
         TO* yp = y + ((((int64_t)n * D + gz) * H + gy) * W + gx) * ycs + co0;
         bool vec = (co0 + COT <= Cout) && (ycs % 8 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
@@ -242,35 +246,35 @@ inline int wgrad_nsb(int Cin, int Cout, Geo g) {
 
 size_t conv3_direct_pack_floats(int Cin, int Cout) { return (size_t)cdiv(Cout, COT) * COT * Cin * 27; }
 
-int conv3_direct_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad, hipStream_t s) {
+int conv3_direct_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad, hipStream_t s, const float* scale) {
     int64_t n = (int64_t)conv3_direct_pack_floats(Cin, Cout) + (int64_t)conv3_direct_pack_floats(Cout, Cin);
-    pack_kernel<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, s>>>(w, Cin, Cout, wp_fwd, wp_dgrad);
+    pack_kernel<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, s>>>(w, Cin, Cout, wp_fwd, wp_dgrad, scale);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
 
 template <typename TI, typename TO>
 static int launch_fwd(const void* x, int xcs, int Cin, const float* wp, const float* bias, void* y, int ycs, int Cout,
-                      Geo g, hipStream_t s) {
+                      Geo g, hipStream_t s, int relu) {
     int tz = cdiv(g.D, TZ), ty = cdiv(g.H, TY), tx = cdiv(g.W, TX);
     dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)cdiv(Cout, COT));
     bool v8 = Cin % 8 == 0 && xcs % 8 == 0 && ((uintptr_t)x % 16 == 0);
     if (v8)
-        conv3_direct_kernel<TI, TO, 8><<<grid, BLK, 0, s>>>((const TI*)x, xcs, Cin, wp, bias, (TO*)y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx);
+        conv3_direct_kernel<TI, TO, 8><<<grid, BLK, 0, s>>>((const TI*)x, xcs, Cin, wp, bias, (TO*)y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, relu);
     else
-        conv3_direct_kernel<TI, TO, 1><<<grid, BLK, 0, s>>>((const TI*)x, xcs, Cin, wp, bias, (TO*)y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx);
+        conv3_direct_kernel<TI, TO, 1><<<grid, BLK, 0, s>>>((const TI*)x, xcs, Cin, wp, bias, (TO*)y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, relu);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
 
 int conv3_direct_fwd(int in_dtype, int out_dtype, const void* x, int xcs, int Cin, const float* wp, const float* bias,
-                     void* y, int ycs, int Cout, Geo g, hipStream_t s) {
+                     void* y, int ycs, int Cout, Geo g, hipStream_t s, int relu) {
     MI3D_CHECK_ARG(Cin >= 1 && Cout >= 1 && xcs >= Cin && ycs >= Cout, "conv3_direct_fwd: bad channels");
     MI3D_CHECK_ARG((int64_t)g.N * cdiv(g.D, TZ) * cdiv(g.H, TY) * cdiv(g.W, TX) < (1ll << 31), "conv3: grid too large");
-    if (in_dtype == MI3D_F32 && out_dtype == MI3D_F32) return launch_fwd<float, float>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s);
-    if (in_dtype == MI3D_F32 && out_dtype == MI3D_BF16) return launch_fwd<float, bf16>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s);
-    if (in_dtype == MI3D_BF16 && out_dtype == MI3D_BF16) return launch_fwd<bf16, bf16>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s);
-    return launch_fwd<bf16, float>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s);
+    if (in_dtype == MI3D_F32 && out_dtype == MI3D_F32) return launch_fwd<float, float>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s, relu);
+    if (in_dtype == MI3D_F32 && out_dtype == MI3D_BF16) return launch_fwd<float, bf16>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s, relu);
+    if (in_dtype == MI3D_BF16 && out_dtype == MI3D_BF16) return launch_fwd<bf16, bf16>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s, relu);
+    return launch_fwd<bf16, float>(x, xcs, Cin, wp, bias, y, ycs, Cout, g, s, relu);
 }
 
 size_t conv3_direct_wgrad_ws_floats(int Cin, int Cout, Geo g) {

@@ -79,9 +79,11 @@ __global__ __launch_bounds__(BLK) void pack_all_kernel(PackJobs J) {
         int mode_f = J.j[ji].mode_f, mode_d = J.j[ji].mode_d;
         int CIBN = Cin / 16, COBN = Cout / 16;
         int cib = lb % CIBN, cob = lb / CIBN;
+        const float* __restrict__ sc = J.j[ji].scale;          // inference: per-output-channel BatchNorm scale (forward image)
         for (int idx = threadIdx.x; idx < 16 * 432; idx += BLK) {
             int row = idx / 432, k = idx - row * 432;
-            wl[row * PK_LD + k] = w[((int64_t)(cob * 16 + row) * Cin + cib * 16) * 27 + k];
+            float v = w[((int64_t)(cob * 16 + row) * Cin + cib * 16) * 27 + k];
+            wl[row * PK_LD + k] = sc ? v * sc[cob * 16 + row] : v;
         }
         __syncthreads();
         for (int q = threadIdx.x; q < 2 * 14 * 64; q += BLK) {
@@ -143,7 +145,7 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
                                                 const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                 bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
                                                 int tilesZ, int tilesY, int tilesX, float* __restrict__ part,
-                                                char* ext_lds = nullptr) {
+                                                char* ext_lds = nullptr, int relu = 0) {
     constexpr int BY = 16 / BX;
     constexpr int TY = TYB * BY, TX = TXB * BX;
     constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
@@ -322,6 +324,7 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = acc[r][c][j] + (bias ? bias[(cobBase + c) * 16 + g * 4 + j] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);           // inference: BatchNorm folded into (weights, bias), ReLU here
                 o[j] = (bf16)v;
                 if (STATS && ok) { float q = (float)o[j]; s1[c][j] += q; s2[c][j] += q * q; }
             }
@@ -353,9 +356,9 @@ template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK>
 __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                          const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                          bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
-                                                         int tilesZ, int tilesY, int tilesX, float* __restrict__ part) {
+                                                         int tilesZ, int tilesY, int tilesX, float* __restrict__ part, int relu) {
     conv3_mfma_body<TZ, TYB, TXB, BX, COB, STATS, SPLITK>(real_bid(), x, xcs, Cin, wp, bias, y, ycs, CoutTotal, D, H, W, tilesZ,
-                                                          tilesY, tilesX, part);
+                                                          tilesY, tilesX, part, nullptr, relu);
 }
 
 // ------------------------------------------------------------------------------------------ persistent variant
@@ -372,7 +375,8 @@ __device__ __forceinline__ void conv3_mfma_persist_body(Bid bid_, const bf16* __
                                                         const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                         bf16* __restrict__ y, int ycs, int D, int H, int W,
                                                         int tilesZ, int tilesY, int tilesX, int ntiles,
-                                                        float* __restrict__ part, Halves xh, Halves yh, char* ext_lds = nullptr) {
+                                                        float* __restrict__ part, Halves xh, Halves yh, char* ext_lds = nullptr,
+                                                        int relu = 0) {
     constexpr int TZ = 4, TY = 8, TX = 16, IZ = 6, IY = 10, IX = 18, MB = 8;
     constexpr int NVOX = IZ * IY * IX, NIT = (NVOX * 2 + BLK - 1) / BLK;
     constexpr int CoutTotal = COB * 16;
@@ -584,7 +588,9 @@ __device__ __forceinline__ void conv3_mfma_persist_body(Bid bid_, const bf16* __
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    o[j] = (bf16)(acc[r][c][j] + bv[c][j]);
+                    float v = acc[r][c][j] + bv[c][j];
+                    if (relu) v = fmaxf(v, 0.f);
+                    o[j] = (bf16)v;
                     if (STATS) { float q = ok ? (float)o[j] : 0.f; s1[c][j] += q; s2[c][j] = fmaf(q, q, s2[c][j]); }
                 }
                 if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs + c * 16 + (c >= yh.split ? yh.delta : 0)) = o;
@@ -616,8 +622,9 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
                                                                     const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                                     bf16* __restrict__ y, int ycs, int D, int H, int W,
                                                                     int tilesZ, int tilesY, int tilesX, int ntiles,
-                                                                    float* __restrict__ part, Halves xh, Halves yh) {
-    conv3_mfma_persist_body<COB, NCH, STATS>(real_bid(), x, xcs, wp, bias, y, ycs, D, H, W, tilesZ, tilesY, tilesX, ntiles, part, xh, yh);
+                                                                    float* __restrict__ part, Halves xh, Halves yh, int relu) {
+    conv3_mfma_persist_body<COB, NCH, STATS>(real_bid(), x, xcs, wp, bias, y, ycs, D, H, W, tilesZ, tilesY, tilesX, ntiles, part, xh, yh,
+                                             nullptr, relu);
 }
 
 constexpr int PERSIST_WGS = 512;
@@ -637,7 +644,7 @@ inline int persist_grid(int Cin, int Cout, Geo g) {
 
 // y[v][c] = bf16(bias[c] + sum_k part[k][v][c]); 8 channels per thread
 __device__ __forceinline__ void splitk_finish_body(int blk, int nblk, const float* __restrict__ part, int ksplit, int64_t M, int C,
-                                                   const float* __restrict__ bias, bf16* __restrict__ y, int ycs) {
+                                                   const float* __restrict__ bias, bf16* __restrict__ y, int ycs, int relu = 0) {
     int G8 = C / 8;
     int64_t total = M * G8;
     for (int64_t idx = (int64_t)blk * BLK + threadIdx.x; idx < total; idx += (int64_t)nblk * BLK) {
@@ -651,31 +658,35 @@ __device__ __forceinline__ void splitk_finish_body(int blk, int nblk, const floa
             f32x4 u = *reinterpret_cast<const f32x4*>(p), w = *reinterpret_cast<const f32x4*>(p + 4);
             a[0] += u[0]; a[1] += u[1]; a[2] += u[2]; a[3] += u[3]; a[4] += w[0]; a[5] += w[1]; a[6] += w[2]; a[7] += w[3];
         }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = fmaxf(a[j], 0.f);
+        }
         st8<bf16>(y + v * ycs + c0, a);
     }
 }
 
 __global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restrict__ part, int ksplit, int64_t M, int C,
-                                                            const float* __restrict__ bias, bf16* __restrict__ y, int ycs) {
-    splitk_finish_body((int)blockIdx.x, (int)gridDim.x, part, ksplit, M, C, bias, y, ycs);
+                                                            const float* __restrict__ bias, bf16* __restrict__ y, int ycs, int relu) {
+    splitk_finish_body((int)blockIdx.x, (int)gridDim.x, part, ksplit, M, C, bias, y, ycs, relu);
 }
 
 template <int TZ, int TYB, int TXB, int BX, int COB>
 int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bias, bf16* y, int ycs, int Cout, Geo g,
-               float* part, int ksplit, float* skws, hipStream_t s, bool defer_finish = false) {
+               float* part, int ksplit, float* skws, hipStream_t s, bool defer_finish = false, int relu = 0) {
     constexpr int TY = TYB * (16 / BX), TX = TXB * BX;
     int tz = cdiv(g.D, TZ), ty = cdiv(g.H, TY), tx = cdiv(g.W, TX);
     dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)), (unsigned)ksplit);
     if (ksplit > 1) {
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, nullptr, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, skws);
+        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, nullptr, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, skws, 0);
         MI3D_LAUNCH_CHECK();
         if (defer_finish) return 0;
         int64_t tot = g.M() * (Cout / 8);
-        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ksplit, g.M(), Cout, bias, y, ycs);
+        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ksplit, g.M(), Cout, bias, y, ycs, relu);
     } else if (part)
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part);
+        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part, relu);
     else
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr);
+        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr, relu);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -711,10 +722,10 @@ int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dg
     return 0;
 }
 
-int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g) {
+int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g, const float* scale) {
     MI3D_CHECK_ARG(J.n < MAX_PACK_JOBS && Cin % 16 == 0 && Cout % 16 == 0, "pack_all: too many jobs / bad channels");
     PackJob& j = J.j[J.n++];
-    j = PackJob{w, wp_fwd, wp_dgrad, Cin, Cout, 0, persist_ok(Cin, Cout, g) ? 1 : 0, persist_ok(Cout, Cin, g) ? 1 : 0, J.nblocks};
+    j = PackJob{w, wp_fwd, wp_dgrad, Cin, Cout, 0, persist_ok(Cin, Cout, g) ? 1 : 0, persist_ok(Cout, Cin, g) ? 1 : 0, J.nblocks, scale};
     J.nblocks += (Cin / 16) * (Cout / 16);
     return 0;
 }
@@ -753,7 +764,7 @@ bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g) { return pick_ksplit(Cin, 
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g) { return persist_ok(Cin, Cout, g); }
 
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
-                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred) {
+                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred, int relu) {
     if (ks_deferred) *ks_deferred = 0;
     MI3D_CHECK_ARG((!xh.on() && !yh.on()) || persist_ok(Cin, Cout, g), "conv3_mfma_fwd: planar halves need the persistent kernel");
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, ycs), "conv3_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
@@ -764,8 +775,8 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         int tz = cdiv(g.D, 4), ty = cdiv(g.H, 8), tx = cdiv(g.W, 16), nt = g.N * tz * ty * tx, grid = persist_grid(Cin, Cout, g);
 #define PK(COB_, NCH_)                                                                                                         \
         do {                                                                                                                   \
-            if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh); \
-            else conv3_mfma_persist_kernel<COB_, NCH_, false><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh); \
+            if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu); \
+            else conv3_mfma_persist_kernel<COB_, NCH_, false><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh, relu); \
         } while (0)
         if (Cin == 16 && Cout == 16) PK(1, 1);
         else if (Cin == 32) PK(1, 2);
@@ -777,13 +788,13 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     int ks = skws ? pick_ksplit(Cin, Cout, g) : 1;
     if (ks > 1) MI3D_CHECK_ARG(ycs % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv3_mfma_fwd: split-K needs 16-B aligned output rows");
     if (big_geo(g)) {
-        if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s);
-        return launch_cfg<4, 8, 1, 16, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s);
+        if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s, false, relu);
+        return launch_cfg<4, 8, 1, 16, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s, false, relu);
     }
     bool defer = ks > 1 && ks_deferred;
     if (defer) *ks_deferred = ks;
-    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer);
-    return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer);
+    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer, relu);
+    return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer, relu);
 }
 
 // =================================================================================================== wgrad
@@ -1161,7 +1172,8 @@ constexpr int C1F_LD = 24;                         // row pitch (elements) of on
 __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                                 const float* __restrict__ bias, bf16* __restrict__ y, int ycs,
                                                                 int Cout, int N, int D, int H, int W, int tilesZ, int tilesY,
-                                                                int tilesX, float* __restrict__ part) {
+                                                                int tilesX, float* __restrict__ part,
+                                                                const float* __restrict__ wscale, int relu) {
     constexpr int ROWS = WIZ * WIY;                 // 60 halo rows
     __shared__ __attribute__((aligned(16))) bf16 xsh[4 * ROWS * C1F_LD];
     __shared__ float red[4][16][2];
@@ -1173,11 +1185,12 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
     bf16x8 wa, wb;
     {
         const float* wr = wgt + (int64_t)(co0 + vn) * 27;
+        float sc = wscale ? wscale[co0 + vn] : 1.f;           // inference: BatchNorm scale folded into the filter
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             int pair = 2 * kg + (j >> 2), dx = j & 3;
-            wa[j] = (bf16)((dx < 3) ? wr[pair * 3 + dx] : 0.f);
-            wb[j] = (bf16)((kg == 0 && j < 3) ? wr[24 + j] : 0.f);
+            wa[j] = (bf16)((dx < 3) ? wr[pair * 3 + dx] * sc : 0.f);
+            wb[j] = (bf16)((kg == 0 && j < 3) ? wr[24 + j] * sc : 0.f);
         }
     }
     float bv[4];
@@ -1231,7 +1244,9 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                o[j] = (bf16)(acc[j] + bv[j]);
+                float v = acc[j] + bv[j];
+                if (relu) v = fmaxf(v, 0.f);
+                o[j] = (bf16)v;
                 float q = ok ? (float)o[j] : 0.f;
                 s1[j] += q; s2[j] = fmaf(q, q, s2[j]);
             }
@@ -1466,7 +1481,7 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     }
     if (ks > 1) {
         int64_t tot = g.M() * (Cin / 8);
-        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ks, g.M(), Cin, nullptr, (bf16*)dx, dxcs);
+        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ks, g.M(), Cin, nullptr, (bf16*)dx, dxcs, 0);
         MI3D_LAUNCH_CHECK();
     }
     return wgrad_slab_sum(wgws, c.nsb, Cin, Cout, dW, db, accumulate, s, pend);
@@ -1496,11 +1511,11 @@ int conv3_c1_fwd_stat_blocks(Geo g) {
     return (int)(ntiles < 1024 ? ntiles : 1024);
 }
 int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,
-                      hipStream_t s) {
+                      hipStream_t s, const float* wscale, int relu) {
     MI3D_CHECK_ARG(Cout % 16 == 0 && ycs % 4 == 0 && ((uintptr_t)y % 8) == 0, "conv3_c1_fwd_mfma: unsupported channels");
     dim3 grid((unsigned)conv3_c1_fwd_stat_blocks(g), (unsigned)(Cout / 16));
     conv3_c1_fwd_mfma_kernel<<<grid, BLK, 0, s>>>(x, w, bias, (bf16*)y, ycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ),
-                                                  cdiv(g.H, WTY), cdiv(g.W, WTX), part);
+                                                  cdiv(g.H, WTY), cdiv(g.W, WTX), part, wscale, relu);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -16,10 +16,11 @@ struct Geo {
 // ---- 3x3x3 convolution, direct (any channel count, any dtype; fp32 FMA) -------------- conv3_direct.hip
 // Reference: nn.Conv3d(k=3,p=1) models/unet.py:11,15.  Weights arrive in torch layout (Cout,Cin,3,3,3) fp32.
 size_t conv3_direct_pack_floats(int Cin, int Cout);          // size of ONE packed operand (fwd or dgrad)
-int conv3_direct_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad, hipStream_t s);
+int conv3_direct_pack(const float* w, int Cin, int Cout, float* wp_fwd, float* wp_dgrad, hipStream_t s,
+                      const float* scale = nullptr);     // scale: per-output-channel factor of the forward operand
 // y[v,co] = bias[co] + sum_{tap,ci} x[v+tap,ci] * wp ;  dgrad = same call with wp_dgrad, (Cin,Cout) swapped, bias NULL
 int conv3_direct_fwd(int in_dtype, int out_dtype, const void* x, int xcs, int Cin, const float* wp,
-                     const float* bias, void* y, int ycs, int Cout, Geo g, hipStream_t s);
+                     const float* bias, void* y, int ycs, int Cout, Geo g, hipStream_t s, int relu = 0);
 // dW[co,ci,tap] (+)= sum_v dy[v,co] x[v+tap,ci] ; db[co] (+)= sum_v dy[v,co].  Deterministic slab reduction.
 size_t conv3_direct_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_direct_wgrad(int x_dtype, int dy_dtype, const void* x, int xcs, int Cin, const void* dy, int dycs,
@@ -32,10 +33,12 @@ size_t conv3_mfma_pack_elems(int Cin, int Cout);             // bf16 elements of
 int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g, hipStream_t s);
 // All weight packs of a network in ONE launch (every kernel node of the step graph costs ~4.5 us of dispatch floor):
 // jobs are appended on the host, the kernel finds its job from the block index.
-struct PackJob { const float* w; void* a; void* b; int Cin, Cout, kind, mode_f, mode_d, blk0; };   // kind 0 conv3, 1 upconv
+// scale (conv3 only, may be NULL): per-output-channel factor folded into the FORWARD image (inference: BatchNorm scale)
+struct PackJob { const float* w; void* a; void* b; int Cin, Cout, kind, mode_f, mode_d, blk0; const float* scale; };   // kind 0 conv3, 1 upconv
 constexpr int MAX_PACK_JOBS = 32;
 struct PackJobs { int n, nblocks; PackJob j[MAX_PACK_JOBS]; };
-int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g);
+int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g,
+                       const float* scale = nullptr);
 int pack_all_add_upconv(PackJobs& J, const float* w, int Cin, int Cout, void* wp);
 int pack_all_launch(const PackJobs& J, hipStream_t s);
 int conv3_mfma_stat_blocks(int Cin, int Cout, Geo g);                           // partials written when `part` != NULL
@@ -49,7 +52,8 @@ struct Halves { int split = 1 << 30; int64_t delta = 0; bool on() const { return
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g);          // forward (Cin,Cout) launch can take Halves x / y
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
                    Geo g, float* part, float* skws, hipStream_t s, Halves xh = Halves(), Halves yh = Halves(),
-                   int* ks_deferred = nullptr);
+                   int* ks_deferred = nullptr, int relu = 0);
+// relu != 0: y = max(0, conv + bias) -- the inference path, where BatchNorm is folded into (weights, bias)
 // ks_deferred != NULL: a split-K launch leaves its fp32 partials in skws ([ks][M][Cout]) WITHOUT the finishing pass and
 // reports ks there (0 = y was written as usual); the caller finishes (bn_train_stats_splitk, fused with the statistics)
 
@@ -71,7 +75,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
 // first layer (Cin = 1, fp32 input) forward on the matrix cores (K = taps); optional BN partial sums like conv3_mfma_fwd
 int conv3_c1_fwd_stat_blocks(Geo g);
 int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,
-                      hipStream_t s);
+                      hipStream_t s, const float* wscale = nullptr, int relu = 0);
 int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db, int accumulate,
                         float* ws, size_t ws_floats, hipStream_t s, SlabJob* pend = nullptr);
 
@@ -88,6 +92,14 @@ int bn_train_finalize(const float* part, int nblk, int C, int64_t M, const float
                       float eps, float* stat, hipStream_t s);
 int bn_eval_stats(int C, const float* gamma, const float* beta, const float* running_mean,
                   const float* running_var, float eps, float* stat, hipStream_t s);
+// Inference: eval-mode BatchNorm folded into the preceding conv, for ALL layers of a network in ONE launch:
+//   scale[c] = gamma/sqrt(running_var + eps)   (multiplied into the filter at pack time)
+//   fbias[c] = (conv_bias - running_mean)*scale + beta
+struct BnFoldJob { const float* gamma; const float* beta; const float* rm; const float* rv; const float* conv_bias;
+                   float* scale; float* fbias; int C; };
+constexpr int MAX_FOLD_JOBS = 2 * (2 * 6 + 1);
+struct BnFoldJobs { int n; float eps; BnFoldJob j[MAX_FOLD_JOBS]; };
+int bn_fold_all(const BnFoldJobs& J, hipStream_t s);
 // z = drop[n,c] * relu(a*y + b)      (drop == NULL -> 1)
 int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* stat,
                        const float* drop, void* z, int zcs, hipStream_t s);

@@ -357,11 +357,45 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
     return 0;
 }
 
+// inference forward of block b: BatchNorm (running statistics) folded into the conv (scale in the packed filter, bias
+// replaced), ReLU in the conv epilogue, output written straight to where the activated tensor lives -- no raw conv
+// output, no statistics, no separate normalisation pass.  stat[0..C) = scale, stat[C..2C) = folded bias (bn_fold_all).
+int block_infer(const Ctx& c, int b, const float* x) {
+    const Plan& p = c.p;
+    const BlockP& B = p.blk[b];
+    Geo g = p.geo[B.level];
+    const void* xin; int xcs, xdt;
+    block_input(c, b, x, xin, xcs, xdt);
+    void* zout; int zcs;
+    block_output(c, b, zout, zcs);
+    for (int h = 0; h < 2; h++) {
+        const HalfP& H = B.h[h];
+        const void* in = h == 0 ? xin : c.at(B.z1);
+        int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
+        void* zo = h == 0 ? c.at(B.z1) : zout;
+        int zocs = h == 0 ? H.Cout : zcs;
+        const float* scale = c.at<float>(H.stat);
+        const float* fbias = scale + H.Cout;
+        if (H.mfma) {
+            MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), fbias, zo, zocs, H.Cout, g, nullptr,
+                                    (zocs % 8 == 0 && ((uintptr_t)zo % 16) == 0) ? c.at<float>(p.skws) : nullptr, c.s,
+                                    (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), nullptr, 1));
+        } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT") &&
+                   !getenv("MI3D_NO_C1_MFMA")) {
+            MI3D_TRY(conv3_c1_fwd_mfma((const float*)in, c.P(H.pidx), fbias, zo, zocs, H.Cout, g, nullptr, c.s, scale, 1));
+        } else {
+            MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), nullptr, c.s, scale));
+            MI3D_TRY(conv3_direct_fwd(idt, p.dt, in, ics, H.Cin, c.at<float>(H.wpf), fbias, zo, zocs, H.Cout, g, c.s, 1));
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 1; }
+int mi3d_abi_version(void) { return 2; }
 
 int mi3d_unet_num_params(const mi3d_unet_desc* d) { return d ? 8 * (2 * d->n_levels + 1) + 2 * d->n_levels + 2 : -1; }
 int mi3d_unet_num_buffers(const mi3d_unet_desc* d) { return d ? 6 * (2 * d->n_levels + 1) : -1; }
@@ -445,6 +479,66 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
                                  p.catcs(l), p.C[l], p.geo[l + 1], c.s));
         }
         MI3D_TRY(block_forward(c, L + 1 + i, x, buffers, drop_scales, training));
+    }
+    MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
+                       d->out_channels, d->N, p.geo[0].V(), c.s));
+    return 0;
+}
+
+int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
+                    float* logits, float* gap_out, void* workspace, size_t workspace_bytes, void* stream) {
+    Plan p;
+    MI3D_TRY(build_plan(d, p));
+    MI3D_CHECK_ARG(x && params && buffers && logits && workspace, "mi3d_unet_infer: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
+    MI3D_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
+    int L = p.L;
+    if (d->in_channels > 1)
+        MI3D_TRY(ncdhw_to_ndhwc(p.dt, x, c.at(p.xcl), d->in_channels, d->in_channels, d->N, p.geo[0].V(), c.s));
+    {   // launch 1: every BatchNorm folded; launch 2: every MFMA weight pack, BatchNorm scale multiplied in
+        BnFoldJobs F;
+        F.n = 0; F.eps = d->bn_eps;
+        PackJobs J;
+        J.n = 0; J.nblocks = 0;
+        for (int b = 0; b < p.nblk; b++)
+            for (int h = 0; h < 2; h++) {
+                const HalfP& H = p.blk[b].h[h];
+                MI3D_CHECK_ARG(buffers[H.bidx] && buffers[H.bidx + 1], "mi3d_unet_infer needs running statistics");
+                float* scale = c.at<float>(H.stat);
+                F.j[F.n++] = BnFoldJob{c.P(H.pidx + 2), c.P(H.pidx + 3), (const float*)buffers[H.bidx], (const float*)buffers[H.bidx + 1],
+                                       c.P(H.pidx + 1), scale, scale + H.Cout, H.Cout};
+                if (H.mfma) MI3D_TRY(pack_all_add_conv3(J, c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), p.geo[p.blk[b].level], scale));
+            }
+        for (int i = 0; i < L; i++) {
+            int l = L - 1 - i;
+            if (p.up_mfma[i]) MI3D_TRY(pack_all_add_upconv(J, c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i])));
+        }
+        MI3D_TRY(bn_fold_all(F, c.s));
+        MI3D_TRY(pack_all_launch(J, c.s));
+        c.packed = true;
+    }
+    for (int l = 0; l < L; l++) {
+        MI3D_TRY(block_infer(c, l, x));
+        MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), p.catcs(l), p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
+    }
+    MI3D_TRY(block_infer(c, L, x));
+    if (gap_out) MI3D_TRY(gap_fwd(p.dt, c.at(p.zb), p.C[L], p.C[L], d->N, p.geo[L].V(), gap_out, c.s));
+    for (int i = 0; i < L; i++) {
+        int l = L - 1 - i;
+        float* wf = c.at<float>(p.upw[i]);
+        float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
+        const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
+        char* catl = c.at<char>(p.cat[l]);
+        if (p.up_mfma[i]) {
+            MI3D_TRY(upconv2_mfma_fwd(uin, 2 * p.C[l], 2 * p.C[l], c.at(p.upw[i]), c.P(p.up_pidx(i) + 1),
+                                      catl + p.half_off(l), p.catcs(l), p.C[l], p.geo[l + 1], c.s));
+        } else {
+            MI3D_TRY(upconv2_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], wf, wb, c.s));
+            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + p.half_off(l),
+                                 p.catcs(l), p.C[l], p.geo[l + 1], c.s));
+        }
+        MI3D_TRY(block_infer(c, L + 1 + i, x));
     }
     MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
                        d->out_channels, d->N, p.geo[0].V(), c.s));

@@ -146,6 +146,21 @@ class _UNetFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+def _infer(model, x, desc, hold, params, want_gap):
+    dev = x.device
+    ws = torch.empty(hold.ws_bytes, dtype=torch.uint8, device=dev)
+    logits = torch.empty((desc.N, desc.out_channels, desc.D, desc.H, desc.W), dtype=torch.float32, device=dev)
+    gap = None
+    if want_gap:
+        gap = torch.empty((desc.N, 2 * desc.features[desc.n_levels - 1]), dtype=torch.float32, device=dev)
+    ptab = ptr_table([p.data_ptr() for p in params])
+    btab = ptr_table([b.data_ptr() for b in hold.buffers])
+    call("mi3d_unet_infer", C.byref(desc), ptr(x), ptab, btab, ptr(logits), ptr(gap), ptr(ws), hold.ws_bytes, stream_ptr())
+    if model.output_activation is not None:
+        logits = model.output_activation(logits)
+    return logits, gap
+
+
 def unet_forward(model, x, want_gap=False):
     """Shared body of unet.UNet3D.forward and unet_dann.UNet3D.forward."""
     _lib.require_cuda(x, "UNet3D.forward")
@@ -168,6 +183,10 @@ def unet_forward(model, x, want_gap=False):
     expect = _lib.lib().mi3d_unet_num_params(C.byref(desc))
     if len(params) != expect or len(hold.buffers) != _lib.lib().mi3d_unet_num_buffers(C.byref(desc)):
         raise _lib.Mi3dError(f"module has {len(params)} parameters / {len(hold.buffers)} buffers, plan expects {expect}")
+    if not model.training and not (torch.is_grad_enabled() and any(q.requires_grad for q in params)):
+        # inference (train_unet.py:259-305 evaluate, test_model.py:242-251, the distillation teacher): BatchNorm folded
+        # into the convs, no saved activations, no autograd node
+        return _infer(model, x, desc, hold, params, want_gap)
     drop = None
     p = float(getattr(model, "dropout_rate", 0.0))
     injected = getattr(model, "_mi3d_injected_drop_scales", None)

@@ -416,7 +416,8 @@ class TrainStep(_StepBase):
              ptr(st["logits"]), None, ptr(st["ws"]), st["ws_bytes"], s)
         t_logits = None
         if self.teacher is not None:
-            call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"], None, 0,
+            # frozen teacher (distill_unet.py:109-111): the BatchNorm-folded inference forward
+            call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"],
                  ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], s)
             t_logits = st["t_logits"]
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
@@ -485,7 +486,7 @@ class TrainStep(_StepBase):
         desc = st["desc"]
         s = stream_ptr()
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
-        call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], None, 0, ptr(st["logits"]), None,
+        call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(st["logits"]), None,
              ptr(st["ws"]), st["ws_bytes"], s)
         call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
              C.byref(self.eval_cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),

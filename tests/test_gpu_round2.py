@@ -769,3 +769,46 @@ def test_fused_backward_route_is_exactly_the_unfused_one_at_scale(monkeypatch):
         worst = max(worst, e)
         assert e < 1e-5, (k, e)
     print("fused vs unfused backward at 96^3: worst per-tensor relerr", worst)
+
+
+# ------------------------------------------------------------------------------------------------ inference forward
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_folded_inference_forward(dtype):
+    """mi3d_unet_infer (eval-mode BatchNorm folded into the convs, ReLU in the conv epilogue, no saved activations) against
+    (a) the oracle's eval-mode forward and (b) the unfolded eval-mode kernels (mi3d_unet_forward(training=0): conv, then
+    a separate normalisation pass) on a net with non-trivial running statistics and affine parameters; incl. the GAP
+    feature of models/unet_dann.py:77-79."""
+    from oracle import torch_ref
+    m = default_model(unet_dann.UNet3D)
+    gen = torch.Generator().manual_seed(42)
+    with torch.no_grad():
+        for k, b in m.named_buffers():
+            if k.endswith("running_mean"):
+                b.copy_(0.2 * torch.randn(b.shape, generator=gen))
+            if k.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=gen))
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn(p.shape, generator=gen))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    m.compute_dtype = dtype
+    x, _ = synth(2, 32, 8)
+    with torch.no_grad():
+        lo, gap = m(x.to(DEV), return_features=True)           # folded inference path
+    ref, rgap, _ = torch_ref.unet3d_forward(sd, x, train=False, return_features=True)
+    fp32 = dtype == torch.float32
+    assert relerr(lo.cpu(), ref) < (2e-5 if fp32 else 3e-2)
+    assert relerr(gap.cpu(), rgap) < (2e-5 if fp32 else 3e-2)
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    with torch.enable_grad():                                   # parameters require grad -> the unfolded eval kernels
+        lu, gu = m(x.to(DEV), return_features=True)
+    assert lu.grad_fn is not None and lo.grad_fn is None
+    assert relerr(lo.cpu(), lu.detach().cpu()) < (2e-5 if fp32 else 3e-2)
+    assert relerr(gap.cpu(), gu.detach().cpu()) < (2e-5 if fp32 else 3e-2)
+    for k, v in m.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k                 # inference never touches the BN buffers
+    # argmax agreement of the segmentation (the output that matters at inference, test_model.py:253)
+    agree = (lo.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
+    assert agree > (0.9999 if fp32 else 0.99), agree
