@@ -116,11 +116,16 @@ int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, 
                           float momentum, float eps, float* stat, float* ws, hipStream_t s);
 
 // ---- MaxPool3d(2,2) ------------------------------------------------------------------------ pool.hip
-// Reference: models/unet.py:40,71.  g = INPUT geometry (even D,H,W required).
+// Reference: models/unet.py:40,71.  g = INPUT geometry; odd sides floor like nn.MaxPool3d (last slice in no window).
 int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int pcs, hipStream_t s);
 // dz = dskip (or 0) + route(dp) to the first max in (d,h,w) scan order
 int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs,
                  void* dz, int dzcs, int C, Geo g, hipStream_t s);
+
+// F.interpolate(x, size=...) nearest, models/unet.py:81-83 (volume sides not divisible by 2^levels).  gi = input
+// geometry, go = output geometry; backward is the gather-form adjoint (deterministic)
+int nearest_resize_fwd(int dtype, const void* x, int xcs, int C, Geo gi, void* y, int ycs, Geo go, hipStream_t s);
+int nearest_resize_bwd(int dtype, const void* gy, int gycs, int C, Geo go, void* gx, int gxcs, Geo gi, hipStream_t s);
 
 // ---- ConvTranspose3d(k=2,s=2) ------------------------------------------------------------ upconv.hip
 // Reference: models/unet.py:56-58,79.  Weight torch layout (Cin,Cout,2,2,2).  g = INPUT geometry.

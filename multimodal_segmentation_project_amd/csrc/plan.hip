@@ -44,6 +44,11 @@ struct Plan {
     // instead of one interleaved [M][2C] tensor.  With C = 16 the interleaved halves are 32 B pieces of 64 B rows and
     // every kernel that touches ONE half (bn apply, max-pool fwd/bwd, upconv fwd/bwd) wastes half of each line.
     bool planar[MAXL];
+    // resize[l]: the transposed conv's output (2x the level below) is smaller than the skip at level l (odd side somewhere
+    // above) -> it goes to uptmp and is nearest-resized into the concat buffer (models/unet.py:81-83)
+    bool resize[MAXL];
+    size_t uptmp;
+    Geo up_geo(int l) const { return Geo{geo[l + 1].N, 2 * geo[l + 1].D, 2 * geo[l + 1].H, 2 * geo[l + 1].W}; }
     int catcs(int l) const { return planar[l] ? C[l] : 2 * C[l]; }
     size_t half_off(int l) const { return (planar[l] ? (size_t)geo[l].M() * C[l] : (size_t)C[l]) * esz; }   // bytes to the up half
     Halves halves(int l) const {
@@ -72,10 +77,10 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     p.L = d->n_levels;
     p.dt = d->dtype;
     p.esz = d->dtype == MI3D_F32 ? 4 : 2;
-    int div = 1 << p.L;
-    // models/unet.py:81-83 falls back to F.interpolate when the sizes do not divide; not on any configured path
-    MI3D_CHECK_ARG(d->D % div == 0 && d->H % div == 0 && d->W % div == 0,
-                   "volume %dx%dx%d not divisible by 2^%d (nearest-interpolate fallback unsupported)", d->D, d->H, d->W, p.L);
+    // sides not divisible by 2^L: MaxPool3d floors and models/unet.py:81-83 nearest-resizes the upsampled tensor to the
+    // skip's shape before the concat (resize[l]); every level must keep at least one voxel per side
+    MI3D_CHECK_ARG((d->D >> p.L) >= 1 && (d->H >> p.L) >= 1 && (d->W >> p.L) >= 1,
+                   "volume %dx%dx%d too small for %d pooling levels", d->D, d->H, d->W, p.L);
     for (int l = 0; l < p.L; l++) {
         MI3D_CHECK_ARG(d->features[l] >= 1 && d->features[l] <= 256, "feature %d out of range", d->features[l]);
         if (l > 0) MI3D_CHECK_ARG(d->features[l] == 2 * d->features[l - 1], "features must double per level");
@@ -84,6 +89,12 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     p.C[p.L] = 2 * d->features[p.L - 1];
     MI3D_CHECK_ARG(p.C[p.L] <= 256, "bottleneck width %d > 256", p.C[p.L]);
     for (int l = 0; l <= p.L; l++) p.geo[l] = Geo{d->N, d->D >> l, d->H >> l, d->W >> l};
+    size_t up_elems = 0;
+    for (int l = 0; l < p.L; l++) {
+        Geo u = p.up_geo(l);
+        p.resize[l] = u.D != p.geo[l].D || u.H != p.geo[l].H || u.W != p.geo[l].W;
+        if (p.resize[l] && (size_t)u.M() * d->features[l] > up_elems) up_elems = (size_t)u.M() * d->features[l];
+    }
 
     for (int l = 0; l < p.L; l++)
         p.planar[l] = p.dt == MI3D_BF16 && p.C[l] % 16 == 0 && conv3_mfma_halves_ok(2 * p.C[l], p.C[l], p.geo[l]) &&
@@ -157,6 +168,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
                                  : upconv2_bwd_ws_floats(2 * p.C[l], p.C[l], p.geo[l + 1]);
         if (wf > wg_floats) wg_floats = wf;
     }
+    p.uptmp = up_elems ? take(up_elems * p.esz) : 0;
     p.xcl = d->in_channels > 1 ? take((size_t)p.geo[0].M() * d->in_channels * p.esz) : 0;
     size_t c1 = conv1_bwd_ws_floats(p.C[0], d->out_channels);
     if (c1 > wg_floats) wg_floats = c1;
@@ -469,15 +481,18 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
         float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
         const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
         char* catl = c.at<char>(p.cat[l]);
+        void* udst = p.resize[l] ? c.at(p.uptmp) : (void*)(catl + p.half_off(l));
+        int udcs = p.resize[l] ? p.C[l] : p.catcs(l);
         if (p.up_mfma[i]) {
             if (!c.packed) MI3D_TRY(upconv2_mfma_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i]), c.s));
             MI3D_TRY(upconv2_mfma_fwd(uin, 2 * p.C[l], 2 * p.C[l], c.at(p.upw[i]), c.P(p.up_pidx(i) + 1),
-                                      catl + p.half_off(l), p.catcs(l), p.C[l], p.geo[l + 1], c.s));
+                                      udst, udcs, p.C[l], p.geo[l + 1], c.s));
         } else {
             MI3D_TRY(upconv2_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], wf, wb, c.s));
-            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + p.half_off(l),
-                                 p.catcs(l), p.C[l], p.geo[l + 1], c.s));
+            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), udst, udcs, p.C[l], p.geo[l + 1], c.s));
         }
+        if (p.resize[l])
+            MI3D_TRY(nearest_resize_fwd(p.dt, udst, udcs, p.C[l], p.up_geo(l), catl + p.half_off(l), p.catcs(l), p.geo[l], c.s));
         MI3D_TRY(block_forward(c, L + 1 + i, x, buffers, drop_scales, training));
     }
     MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
@@ -530,14 +545,17 @@ int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* 
         float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
         const void* uin = i == 0 ? c.at(p.zb) : c.at(p.zd[i - 1]);
         char* catl = c.at<char>(p.cat[l]);
+        void* udst = p.resize[l] ? c.at(p.uptmp) : (void*)(catl + p.half_off(l));
+        int udcs = p.resize[l] ? p.C[l] : p.catcs(l);
         if (p.up_mfma[i]) {
             MI3D_TRY(upconv2_mfma_fwd(uin, 2 * p.C[l], 2 * p.C[l], c.at(p.upw[i]), c.P(p.up_pidx(i) + 1),
-                                      catl + p.half_off(l), p.catcs(l), p.C[l], p.geo[l + 1], c.s));
+                                      udst, udcs, p.C[l], p.geo[l + 1], c.s));
         } else {
             MI3D_TRY(upconv2_pack(c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], wf, wb, c.s));
-            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), catl + p.half_off(l),
-                                 p.catcs(l), p.C[l], p.geo[l + 1], c.s));
+            MI3D_TRY(upconv2_fwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], wf, c.P(p.up_pidx(i) + 1), udst, udcs, p.C[l], p.geo[l + 1], c.s));
         }
+        if (p.resize[l])
+            MI3D_TRY(nearest_resize_fwd(p.dt, udst, udcs, p.C[l], p.up_geo(l), catl + p.half_off(l), p.catcs(l), p.geo[l], c.s));
         MI3D_TRY(block_infer(c, L + 1 + i, x));
     }
     MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
@@ -577,14 +595,20 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
             float* wf = c.at<float>(p.upw[i]);
             float* wb = wf + (size_t)cdiv(p.C[l], 8) * (2 * p.C[l]) * 64;
             char* gcatl = c.at<char>(p.gcat[l]);
+            const void* gup = gcatl + p.half_off(l);
+            int gupcs = p.catcs(l);
+            if (p.resize[l]) {       // adjoint of the nearest resize in front of the concat (models/unet.py:81-83)
+                MI3D_TRY(nearest_resize_bwd(p.dt, gup, gupcs, p.C[l], p.geo[l], c.at(p.uptmp), p.C[l], p.up_geo(l), c.s));
+                gup = c.at(p.uptmp); gupcs = p.C[l];
+            }
             SlabJob* ps = c.pend_slot();
             if (p.up_mfma[i]) {
-                MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gcatl + p.half_off(l), p.catcs(l), p.C[l],
+                MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gup, gupcs, p.C[l],
                                           c.at(p.upw[i]), c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1),
                                           accumulate, wgws, p.wgws_floats, p.geo[l + 1], c.s, ps));
                 c.pend_filled();
             } else
-                MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gcatl + p.half_off(l), p.catcs(l), p.C[l], wb,
+                MI3D_TRY(upconv2_bwd(p.dt, uin, 2 * p.C[l], 2 * p.C[l], gup, gupcs, p.C[l], wb,
                                      c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1), accumulate, wgws,
                                      p.wgws_floats, p.geo[l + 1], c.s));
         } else if (seg == L + 1) {

@@ -77,6 +77,64 @@ __global__ __launch_bounds__(BLK) void maxpool2_bwd_kernel(const T* __restrict__
     }
 }
 
+// odd D/H/W: MaxPool3d floors (the last slice of an odd dimension is in no window) -> those voxels only receive the
+// skip gradient
+template <typename T>
+__global__ __launch_bounds__(BLK) void maxpool2_bwd_border_kernel(const T* __restrict__ dskip, int dskipcs, T* __restrict__ dz, int dzcs,
+                                                                  int C, int N, int D, int H, int W) {
+    int De = D & ~1, He = H & ~1, We = W & ~1;
+    int64_t total = (int64_t)N * D * H * W;
+    for (int64_t v = (int64_t)blockIdx.x * BLK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLK) {
+        int w = (int)(v % W); int64_t r = v / W; int h = (int)(r % H); r /= H; int d = (int)(r % D);
+        if (d < De && h < He && w < We) continue;
+        for (int c = 0; c < C; c++) dz[v * dzcs + c] = dskip ? dskip[v * dskipcs + c] : from_f<T>(0.f);
+    }
+}
+
+// F.interpolate(x, size=skip.shape[2:]) of models/unet.py:81-83 (default mode 'nearest'): src = min(floor(dst * in/out), in-1),
+// computed in float like torch.  Only reached when a volume side is not divisible by 2^levels.
+__device__ __forceinline__ int nn_src(int dst, float scale, int in) {
+    int s = (int)floorf((float)dst * scale);
+    return s < in - 1 ? s : in - 1;
+}
+template <typename T>
+__global__ __launch_bounds__(BLK) void nearest_resize_fwd_kernel(const T* __restrict__ x, int xcs, int C, int N, int Di, int Hi, int Wi,
+                                                                 T* __restrict__ y, int ycs, int Do, int Ho, int Wo) {
+    float sd = (float)Di / Do, sh = (float)Hi / Ho, sw = (float)Wi / Wo;
+    int64_t total = (int64_t)N * Do * Ho * Wo;
+    for (int64_t v = (int64_t)blockIdx.x * BLK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLK) {
+        int w = (int)(v % Wo); int64_t r = v / Wo; int h = (int)(r % Ho); r /= Ho; int d = (int)(r % Do); int n = (int)(r / Do);
+        int64_t src = (((int64_t)n * Di + nn_src(d, sd, Di)) * Hi + nn_src(h, sh, Hi)) * Wi + nn_src(w, sw, Wi);
+        for (int c = 0; c < C; c++) y[v * ycs + c] = x[src * xcs + c];
+    }
+}
+// gx[src] = sum of gy over the destination voxels that read src (gather form: deterministic, no atomics)
+template <typename T>
+__global__ __launch_bounds__(BLK) void nearest_resize_bwd_kernel(const T* __restrict__ gy, int gycs, int C, int N, int Do, int Ho, int Wo,
+                                                                 T* __restrict__ gx, int gxcs, int Di, int Hi, int Wi) {
+    float sd = (float)Di / Do, sh = (float)Hi / Ho, sw = (float)Wi / Wo;
+    int64_t total = (int64_t)N * Di * Hi * Wi;
+    for (int64_t v = (int64_t)blockIdx.x * BLK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLK) {
+        int w = (int)(v % Wi); int64_t r = v / Wi; int h = (int)(r % Hi); r /= Hi; int d = (int)(r % Di); int n = (int)(r / Di);
+        // candidate destinations per dimension: a window around src/scale
+        int d0 = (int)((float)d / sd) - 1, h0 = (int)((float)h / sh) - 1, w0 = (int)((float)w / sw) - 1;
+        for (int c = 0; c < C; c++) {
+            float acc = 0.f;
+            for (int a = d0 < 0 ? 0 : d0; a < Do && a <= d0 + 3; a++) {
+                if (nn_src(a, sd, Di) != d) continue;
+                for (int b = h0 < 0 ? 0 : h0; b < Ho && b <= h0 + 3; b++) {
+                    if (nn_src(b, sh, Hi) != h) continue;
+                    for (int e = w0 < 0 ? 0 : w0; e < Wo && e <= w0 + 3; e++) {
+                        if (nn_src(e, sw, Wi) != w) continue;
+                        acc += to_f<T>(gy[((((int64_t)n * Do + a) * Ho + b) * Wo + e) * gycs + c]);
+                    }
+                }
+            }
+            gx[v * gxcs + c] = from_f<T>(acc);
+        }
+    }
+}
+
 inline int sgrid(int64_t total) {
     int64_t w = (total + BLK - 1) / BLK;
     return (int)(w < 1 ? 1 : (w > 2048 ? 2048 : w));
@@ -85,9 +143,9 @@ inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 }  // namespace
 
 int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int pcs, hipStream_t s) {
-    MI3D_CHECK_ARG(g.D % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0, "maxpool2: odd spatial size %dx%dx%d unsupported", g.D, g.H, g.W);
+    MI3D_CHECK_ARG(g.D >= 2 && g.H >= 2 && g.W >= 2, "maxpool2: volume %dx%dx%d too small", g.D, g.H, g.W);
     MI3D_CHECK_ARG(g.M() / 8 * C < (1ll << 31), "maxpool2: more than 2^31 pooled elements");
-    int64_t nout = g.M() / 8;
+    int64_t nout = (int64_t)g.N * (g.D / 2) * (g.H / 2) * (g.W / 2);          // floor, like nn.MaxPool3d
     DISPATCH_T(dtype, T, {
         if (C % 8 == 0 && zcs % 8 == 0 && pcs % 8 == 0 && al16(z) && al16(p))
             maxpool2_fwd_kernel<T, 8><<<sgrid(nout * (C / 8)), BLK, 0, s>>>((const T*)z, zcs, C, g.N, g.D, g.H, g.W, (T*)p, pcs);
@@ -100,9 +158,10 @@ int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int p
 
 int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs, void* dz,
                  int dzcs, int C, Geo g, hipStream_t s) {
-    MI3D_CHECK_ARG(g.D % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0, "maxpool2_bwd: odd spatial size unsupported");
+    MI3D_CHECK_ARG(g.D >= 2 && g.H >= 2 && g.W >= 2, "maxpool2_bwd: volume too small");
     MI3D_CHECK_ARG(g.M() / 8 * C < (1ll << 31), "maxpool2_bwd: more than 2^31 pooled elements");
-    int64_t nout = g.M() / 8;
+    int64_t nout = (int64_t)g.N * (g.D / 2) * (g.H / 2) * (g.W / 2);
+    bool odd = (g.D | g.H | g.W) & 1;
     DISPATCH_T(dtype, T, {
         bool v8 = C % 8 == 0 && zcs % 8 == 0 && dpcs % 8 == 0 && dzcs % 8 == 0 && (!dskip || dskipcs % 8 == 0) &&
                   al16(z) && al16(dp) && al16(dz) && al16(dskip);
@@ -110,6 +169,27 @@ int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, co
             maxpool2_bwd_kernel<T, 8><<<sgrid(nout * (C / 8)), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);
         else
             maxpool2_bwd_kernel<T, 1><<<sgrid(nout * C), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);
+        MI3D_LAUNCH_CHECK();
+        if (odd) {
+            maxpool2_bwd_border_kernel<T><<<sgrid(g.M()), BLK, 0, s>>>((const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);
+            MI3D_LAUNCH_CHECK();
+        }
+    });
+    return 0;
+}
+
+int nearest_resize_fwd(int dtype, const void* x, int xcs, int C, Geo gi, void* y, int ycs, Geo go, hipStream_t s) {
+    MI3D_CHECK_ARG(gi.N == go.N && C >= 1, "nearest_resize_fwd: bad shapes");
+    DISPATCH_T(dtype, T, {
+        nearest_resize_fwd_kernel<T><<<sgrid(go.M()), BLK, 0, s>>>((const T*)x, xcs, C, gi.N, gi.D, gi.H, gi.W, (T*)y, ycs, go.D, go.H, go.W);
+        MI3D_LAUNCH_CHECK();
+    });
+    return 0;
+}
+int nearest_resize_bwd(int dtype, const void* gy, int gycs, int C, Geo go, void* gx, int gxcs, Geo gi, hipStream_t s) {
+    MI3D_CHECK_ARG(gi.N == go.N && C >= 1, "nearest_resize_bwd: bad shapes");
+    DISPATCH_T(dtype, T, {
+        nearest_resize_bwd_kernel<T><<<sgrid(gi.M()), BLK, 0, s>>>((const T*)gy, gycs, C, go.N, go.D, go.H, go.W, (T*)gx, gxcs, gi.D, gi.H, gi.W);
         MI3D_LAUNCH_CHECK();
     });
     return 0;

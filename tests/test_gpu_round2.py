@@ -812,3 +812,75 @@ def test_bn_folded_inference_forward(dtype):
     # argmax agreement of the segmentation (the output that matters at inference, test_model.py:253)
     agree = (lo.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
     assert agree > (0.9999 if fp32 else 0.99), agree
+
+
+# ------------------------------------------------------------------------------------------------ odd volume sizes
+def test_odd_sizes_reference_fixture(golden):
+    """models/unet.py:81-83: sides not divisible by 2^levels -> MaxPool3d floors, the upsampled tensor is nearest-resized to
+    the skip's shape before the concat.  Reference-run fixture (6x10x7, every side resizes): logits, loss, every gradient,
+    BN buffers, eval logits (the inference forward takes the same route)."""
+    g = golden("oddsize")
+    m = UNet3D(in_channels=2, out_channels=3, features=[4, 8], dropout_rate=0.0)
+    m.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd0/")})
+    m = m.to(DEV).train()
+    m.compute_dtype = torch.float32
+    x, y = t(g["x"]), t(g["y"])
+    logits = m(x)
+    loss = M.combined_loss(logits, y)
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    for k, p in m.named_parameters():
+        ref = g["grad/" + k]
+        if np.abs(ref).max() < 1e-5:
+            assert p.grad.abs().max().item() < 1e-4, k
+        else:
+            assert relerr(p.grad.cpu(), ref) < 2e-3, (k, relerr(p.grad.cpu(), ref))
+    sd = m.state_dict()
+    for k, v in g.items():
+        if k.startswith("sd1/"):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), v, rtol=1e-4, atol=1e-5, err_msg=k)
+    m.eval()
+    with torch.no_grad():
+        le = m(x)
+    np.testing.assert_allclose(le.cpu().numpy(), g["logits_eval"], rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_odd_sizes_default_net_vs_oracle(dtype):
+    """Default net on a 40x36x44 volume (40 -> 20 -> 10 -> 5 -> 2: level 3 resizes 4 -> 5 in D, 36 -> ... -> 4|2: two levels
+    resize in H, 44 -> 22 -> 11 -> 5 -> 2 in W) against the oracle, through TrainStep (graph-captured) and the module path."""
+    from oracle import torch_ref
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 1, 40, 36, 44, generator=gen)
+    y = torch.randint(0, 4, (2, 1, 40, 36, 44), generator=gen)
+    m = default_model().to(DEV).train()
+    m.compute_dtype = dtype
+    lo = m(x.to(DEV))
+    l = M.combined_loss(lo, y.to(DEV))
+    l.backward()
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in default_model().state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    ro, _, _ = torch_ref.unet3d_forward(sd, x, train=True)
+    rl = torch_ref.seg_loss(ro, y, "combined")
+    rl.backward()
+    fp32 = dtype == torch.float32
+    assert relerr(lo.detach().cpu(), ro.detach()) < (2e-4 if fp32 else 3e-2)
+    np.testing.assert_allclose(l.item(), float(rl.detach()), rtol=2e-5 if fp32 else 3e-3)
+    if fp32:
+        for k, p in m.named_parameters():
+            ref = sd[k].grad
+            if float(ref.norm()) > 1e-6:
+                assert relerr(p.grad.cpu(), ref) < FP32_GRAD_TOL, (k, relerr(p.grad.cpu(), ref))
+    # native step on the same odd shape: graph replay == eager
+    outs = []
+    for use_graph in (False, True):
+        mm = default_model().to(DEV).train()
+        ts = TrainStep(mm, compute_dtype=dtype, use_graph=use_graph)
+        ts.load_batch(x.to(DEV), y.to(DEV))
+        outs.append(torch.stack([ts.step_static().clone() for _ in range(2)]).cpu())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(float(outs[0][0, 0]), float(rl.detach()), rtol=2e-5 if fp32 else 3e-3)

@@ -266,3 +266,23 @@ def test_oracle_loop_reproduces_reference_accumulation_quirk(golden):
     sd_p, _, _ = torch_ref.train_loop(sd0, batches, accum=2, zero_grad_quirk=False)
     k = "decoder.3.double_conv.0.weight"
     assert float((sd_p[k] - sd_q[k]).abs().max()) > 1e-4
+
+
+def test_oracle_odd_sizes_match_reference(golden):
+    """Sides not divisible by 2^levels (models/unet.py:81-83 nearest-resize before the concat, MaxPool3d floor): the
+    oracle's functional forward/backward against the reference-run fixture (6x10x7 volume)."""
+    import torch
+    from oracle import torch_ref
+    g = golden("oddsize")
+    sd = {k[4:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("sd0/")}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    logits, _, upd = torch_ref.unet3d_forward(sd, torch.from_numpy(g["x"]), train=True)
+    loss = torch_ref.seg_loss(logits, torch.from_numpy(g["y"]), "combined")
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(loss), g["loss"], rtol=1e-6)
+    for k, v in sd.items():
+        if v.requires_grad:
+            np.testing.assert_allclose(v.grad.numpy(), g["grad/" + k], rtol=1e-3, atol=2e-6, err_msg=k)

@@ -486,6 +486,37 @@ def gen_dropout(ref_unet, ref_metrics, out):
     np.savez_compressed(os.path.join(out, "dropout.npz"), **d)
 
 
+def gen_oddsize(ref_unet, ref_metrics, out):
+    """Volume sides NOT divisible by 2^levels: MaxPool3d floors and UNet3D.forward nearest-resizes the upsampled tensor to
+    the skip's shape (models/unet.py:81-83).  Complete small-net fixture (6x10x7, two levels: every side hits the resize)."""
+    d = {}
+    torch.manual_seed(23)
+    m = ref_unet.UNet3D(in_channels=2, out_channels=3, features=[4, 8], dropout_rate=0.0)
+    g = torch.Generator().manual_seed(231)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+    for k, v in m.state_dict().items():
+        d["sd0/" + k] = npy(v.clone())
+    x = torch.randn(2, 2, 6, 10, 7, generator=g)
+    y = torch.randint(0, 3, (2, 1, 6, 10, 7), generator=g)
+    m.train()
+    logits = m(x)
+    loss = ref_metrics.combined_loss(logits, y)
+    loss.backward()
+    d["x"], d["y"], d["logits"], d["loss"] = npy(x), npy(y), npy(logits), npy(loss)
+    for k, p in m.named_parameters():
+        d["grad/" + k] = npy(p.grad)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            d["sd1/" + k] = npy(v.clone())
+    m.eval()
+    with torch.no_grad():
+        d["logits_eval"] = npy(m(x))
+    np.savez_compressed(os.path.join(out, "oddsize.npz"), **d)
+
+
 def _autocast_yardstick(d, pre, ref_unet, ref_metrics, x, y, fp32_logits, fp32_grads, seed=0):
     """The reference's own bf16 autocast run (accelerate mixed_precision='bf16') vs its fp32 run on the same inputs."""
     torch.manual_seed(seed)
@@ -713,6 +744,7 @@ def main():
     if want("dann"): gen_dann(ref_unet_dann, ref_metrics, ref_train_dann, a.out)
     if want("distill"): gen_distill(ref_unet, ref_metrics, a.out)
     if want("dropout"): gen_dropout(ref_unet, ref_metrics, a.out)
+    if want("oddsize"): gen_oddsize(ref_unet, ref_metrics, a.out)
     if want("loops"): gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
     if want("config2_96"): gen_config2(ref_unet, ref_metrics, a.out)
     if want("config4_dann96"): gen_config4(ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
