@@ -95,9 +95,13 @@ def test_plan_queries_and_argument_errors():
         seen += list(range(r[0], r[1])) + (list(range(r[2], r[3])) if r[2] >= 0 else [])
     assert sorted(seen) == list(range(82))
     # shape the plan cannot run -> error code + message, no crash
-    bad = engine.build_desc(m, torch.zeros(1, 1, 20, 20, 20), torch.float32)
+    # sides not divisible by 16 are planned (models/unet.py:81-83 nearest-resize route) ...
+    odd = engine.build_desc(m, torch.zeros(1, 1, 20, 20, 20), torch.float32)
+    assert lib.mi3d_unet_workspace_bytes(C.byref(odd)) > 0
+    # ... a volume with no voxel left at the bottleneck is not
+    bad = engine.build_desc(m, torch.zeros(1, 1, 20, 12, 20), torch.float32)
     assert lib.mi3d_unet_workspace_bytes(C.byref(bad)) == 0
-    assert b"divisible" in lib.mi3d_last_error()
+    assert b"too small" in lib.mi3d_last_error()
 
 
 def test_no_cpu_fallback():
