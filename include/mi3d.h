@@ -172,6 +172,21 @@ int mi3d_adamw_apply(float* p, const float* g, float* m, float* v, int64_t n, fl
 int mi3d_dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Input pipeline: the per-volume arithmetic of CombinedDataset.__getitem__ (utils/dataloader.py:148-200)
+ * on the device.  in/out: device float (n voxels of ONE volume; in == out allowed); labels int64.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* preprocess_ct, utils/dataloader.py:111-117: clip to [window_min, window_max] (reference: -160, 240), scale to [0,1] */
+int mi3d_preprocess_ct(const float* in, float* out, int64_t n, float window_min, float window_max, void* stream);
+/* preprocess_mri, utils/dataloader.py:128-144: z-score with the population std (+1e-8), clip to the
+ * np.percentile([p_low, p_high]) values (reference: 1, 99; linear interpolation between exact order statistics),
+ * (x - low) / (high - low + 1e-8).  workspace: mi3d_preprocess_mri_workspace_bytes(), 16-byte aligned. */
+size_t mi3d_preprocess_mri_workspace_bytes(void);
+int mi3d_preprocess_mri(const float* in, float* out, int64_t n, float p_low, float p_high, void* workspace, void* stream);
+/* label remaps, utils/dataloader.py:162-181.  kind 0: identity (ts / btcv), 1: AMOS {0:0,1:1,2:3,3:3,6:2, else 0},
+ * 2: CHAOS ranges {[55,70]:2, [110,135]:3, [175,200]:3, [240,255]:1, else 0} */
+int mi3d_remap_labels(const int64_t* in, int64_t* out, int64_t n, int kind, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Per-operator entry points (channels-last activations; used by the parity tests and by stand-alone modules).
  * x/y: `dtype` tensors [N][D][H][W][C] with channel stride xcs/ycs (elements).
  * ---------------------------------------------------------------------------------------------------------- */

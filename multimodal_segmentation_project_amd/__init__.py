@@ -1,6 +1,6 @@
 """MI355X-native (gfx950, hand-written HIP) 3D U-Net training hot path — drop-in for the reference's
 models/unet.py, models/unet_dann.py, utils/metrics.py and the DANN pieces of train_dann.py."""
-from . import checkpoint, engine, metrics, unet, unet_dann, dann  # noqa: F401
+from . import checkpoint, engine, metrics, preprocess, unet, unet_dann, dann  # noqa: F401
 from .engine import set_compute_dtype  # noqa: F401
 from .unet import DoubleConv, UNet3D  # noqa: F401
 from .dann import DomainDiscriminator, GradientReversal, grad_reverse  # noqa: F401

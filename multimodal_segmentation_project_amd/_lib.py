@@ -58,6 +58,10 @@ _SIGS = {
     "mi3d_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, vp]),
     "mi3d_adamw_apply": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, vp, i32, vp]),
     "mi3d_dropout_scales": (i32, [vp, i64, f32, vp, vp]),
+    "mi3d_preprocess_ct": (i32, [vp, vp, i64, f32, f32, vp]),
+    "mi3d_preprocess_mri_workspace_bytes": (sz, []),
+    "mi3d_preprocess_mri": (i32, [vp, vp, i64, f32, f32, vp, vp]),
+    "mi3d_remap_labels": (i32, [vp, vp, i64, i32, vp]),
     "mi3d_conv3_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "mi3d_conv3_forward": (i32, [i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "mi3d_conv3_backward": (i32, [i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32,

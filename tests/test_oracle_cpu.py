@@ -286,3 +286,15 @@ def test_oracle_odd_sizes_match_reference(golden):
     for k, v in sd.items():
         if v.requires_grad:
             np.testing.assert_allclose(v.grad.numpy(), g["grad/" + k], rtol=1e-3, atol=2e-6, err_msg=k)
+
+
+def test_oracle_preprocessing_matches_reference(golden):
+    """oracle/preproc_ref.py (CT window, MRI z-score / percentile clip / min-max, AMOS / CHAOS label remaps) against the
+    outputs of the reference's own CombinedDataset.__getitem__ (fixture preproc.npz)."""
+    from oracle import preproc_ref
+    g = golden("preproc")
+    for name in g["names"]:
+        name = str(name)
+        img = preproc_ref.preprocess(g[f"{name}/image_in"], name)
+        np.testing.assert_allclose(np.asarray(img, np.float32), g[f"{name}/image_out"], rtol=0, atol=1e-7, err_msg=name)
+        np.testing.assert_array_equal(preproc_ref.remap_labels(g[f"{name}/label_in"], name), g[f"{name}/label_out"], err_msg=name)

@@ -517,6 +517,57 @@ def gen_oddsize(ref_unet, ref_metrics, out):
     np.savez_compressed(os.path.join(out, "oddsize.npz"), **d)
 
 
+def gen_preproc(out):
+    """the reference's CombinedDataset.__getitem__ (utils/dataloader.py:148-200) EXECUTED on in-memory
+    volumes: the nibabel stand-in's load() hands back seeded arrays instead of reading NIfTI files, everything after it
+    (CT window, MRI z-score / percentile clip / min-max, AMOS and CHAOS label remaps) is the reference's own code."""
+    import tempfile
+    import utils.dataloader as ref_dl
+    rng = np.random.default_rng(5)
+    shape = (12, 20, 16)
+    vols = {}
+
+    class _Img:
+        def __init__(self, a):
+            self.a = a
+
+        def get_fdata(self):
+            return self.a.astype(np.float64)
+
+    root = tempfile.mkdtemp()
+    names = ["amos_ct", "amos_mri", "chaos_mri", "ts_ct", "btcv"]
+    for ds in names:
+        for sub in ("images", "labels"):
+            os.makedirs(os.path.join(root, ds, sub))
+        ip, lp = os.path.join(root, ds, "images", "v0.nii.gz"), os.path.join(root, ds, "labels", "v0.nii.gz")
+        open(ip, "w").close(); open(lp, "w").close()
+        if ds.endswith("_ct"):
+            img = rng.normal(40.0, 250.0, shape).astype(np.float32)              # HU-like, both window edges exceeded
+        else:
+            img = (rng.gamma(2.0, 120.0, shape) + 30.0 * rng.standard_normal(shape)).astype(np.float32)   # skewed MRI-like
+            img[rng.random(shape) < 0.002] *= 8.0                                # outliers above the 99th percentile
+        if ds.startswith("amos"):
+            lab = rng.integers(0, 16, shape)
+        elif ds.startswith("chaos"):
+            lab = rng.choice([0, 54, 55, 63, 70, 71, 109, 110, 126, 135, 136, 174, 175, 189, 200, 201, 239, 240, 252, 255], shape)
+        else:
+            lab = rng.integers(0, 4, shape)
+        vols[ip], vols[lp] = img, lab.astype(np.float64)
+    sys.modules["nibabel"].load = lambda path: _Img(vols[path])
+    ref_dl.nib.load = sys.modules["nibabel"].load
+    ds_obj = ref_dl.CombinedDataset(root, transform=None)
+    d = {}
+    for i, smp in enumerate(ds_obj.samples):
+        name = smp["dataset_name"]
+        img_t, lab_t = ds_obj[i]
+        d[f"{name}/image_in"] = vols[smp["image_path"]]
+        d[f"{name}/label_in"] = vols[smp["label_path"]].astype(np.int64)
+        d[f"{name}/image_out"] = npy(img_t)[0]
+        d[f"{name}/label_out"] = npy(lab_t)[0]
+    d["names"] = np.array(sorted(n for n in names))
+    np.savez_compressed(os.path.join(out, "preproc.npz"), **d)
+
+
 def _autocast_yardstick(d, pre, ref_unet, ref_metrics, x, y, fp32_logits, fp32_grads, seed=0):
     """The reference's own bf16 autocast run (accelerate mixed_precision='bf16') vs its fp32 run on the same inputs."""
     torch.manual_seed(seed)
@@ -745,6 +796,7 @@ def main():
     if want("distill"): gen_distill(ref_unet, ref_metrics, a.out)
     if want("dropout"): gen_dropout(ref_unet, ref_metrics, a.out)
     if want("oddsize"): gen_oddsize(ref_unet, ref_metrics, a.out)
+    if want("preproc"): gen_preproc(a.out)
     if want("loops"): gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
     if want("config2_96"): gen_config2(ref_unet, ref_metrics, a.out)
     if want("config4_dann96"): gen_config4(ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
