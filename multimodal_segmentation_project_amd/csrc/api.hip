@@ -170,14 +170,16 @@ int mi3d_bn_relu_drop_forward(int dtype, const void* y, int ycs, int C, int64_t 
                               void* workspace, void* stream) {
     MI3D_CHECK_ARG(y && gamma && beta && z && stat && workspace, "mi3d_bn_relu_drop_forward: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    int small_rows = 0;
     if (training)
         MI3D_TRY(bn_train_stats(dtype, y, ycs, C, M, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
-                                eps, stat, (float*)workspace, s));
+                                eps, stat, (float*)workspace, s, &small_rows));
     else {
         MI3D_CHECK_ARG(running_mean && running_var, "eval-mode BN needs running statistics");
         MI3D_TRY(bn_eval_stats(C, gamma, beta, running_mean, running_var, eps, stat, s));
     }
-    return bn_apply_relu_drop(dtype, y, ycs, C, M, V, stat, drop, z, zcs, s);
+    BnSmall sm{(const float*)workspace, small_rows, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps};
+    return bn_apply_relu_drop(dtype, y, ycs, C, M, V, stat, drop, z, zcs, s, small_rows > 0 ? &sm : nullptr);
 }
 int mi3d_bn_relu_drop_backward(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
                                const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,

@@ -141,6 +141,82 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
     }
 }
 
+// Small (deep-level) tensors: the statistics kernel leaves only a few partial rows (<= SMALL_ROWS), and the consumer kernel
+// finishes them in its prologue (every workgroup redundantly, fixed order, double) instead of a finalize launch of its own:
+// every kernel node is a link of the step's dependent chain (~5 us each at these sizes), and an in-kernel "last workgroup
+// finalizes" ticket costs as much as the launch it replaces on 8 XCDs (measured).  Workgroup 0 publishes stat[4][C] for the
+// backward pass and updates the running statistics.
+constexpr int SMALL_ROWS = 128;
+constexpr int MAXC_BN = 256;
+struct BnPart {
+    const float* part; int nrows; int64_t M;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt;
+    float momentum, eps;
+};
+// sum the nrows partial rows [nrows][2][C] per (k, channel): out[k] for threads < C.  Requirements (bn_small_rows):
+// C in {4..256} a power of two, nrows*2*C a multiple of 1024.  The flat array is read as float4, thread t taking elements
+// 4t + 1024 j: its (k, channel quad) is the same for every j, all loads are independent and unconditional (a scalar
+// `acc += part[r]` loop pays an L2 round trip per row: measured 0.3 us each), the per-thread sums are combined through
+// LDS in a fixed order.
+__device__ __forceinline__ void rows_sum(const float* __restrict__ part, int nrows, int C, double* red /* [BLK*4] */, double (&out)[2]) {
+    int J = (nrows * 2 * C) >> 10;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int j = 0;
+    for (; j + 8 <= J; j += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p4[(size_t)(j + u) * BLK];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc[0] += (double)v[u][0]; acc[1] += (double)v[u][1]; acc[2] += (double)v[u][2]; acc[3] += (double)v[u][3]; }
+    }
+    for (; j < J; j++) {
+        f32x4 v = p4[(size_t)j * BLK];
+        acc[0] += (double)v[0]; acc[1] += (double)v[1]; acc[2] += (double)v[2]; acc[3] += (double)v[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) red[threadIdx.x * 4 + i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < C) {
+        int q = C >> 2, c = threadIdx.x, lines = BLK / q;          // thread t holds line t / q (k = line & 1), channels 4*(t % q)..+3
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            double t = 0.0;
+            for (int L = k; L < lines; L += 2) t += red[(L * q + (c >> 2)) * 4 + (c & 3)];
+            out[k] = t;
+        }
+    }
+}
+
+__device__ __forceinline__ void bn_train_coeffs(const BnPart& t, int C, float* stat, float* ab /* [2][MAXC_BN] */, double* red) {
+    double sq[2];
+    rows_sum(t.part, t.nrows, C, red, sq);
+    int c = threadIdx.x;
+    if (c < C) {
+        double mean = sq[0] / (double)t.M;
+        double var = sq[1] / (double)t.M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double inv = 1.0 / sqrt(var + (double)t.eps);
+        float a = (float)((double)t.gamma[c] * inv);
+        float b = (float)((double)t.beta[c] - mean * (double)t.gamma[c] * inv);
+        ab[c] = a;
+        ab[MAXC_BN + c] = b;
+        if (blockIdx.x == 0) {
+            stat[c] = (float)mean;
+            stat[C + c] = (float)inv;
+            stat[2 * C + c] = a;
+            stat[3 * C + c] = b;
+            if (t.running_mean) t.running_mean[c] = (float)((1.0 - t.momentum) * t.running_mean[c] + t.momentum * mean);
+            if (t.running_var) {
+                double unb = t.M > 1 ? var * (double)t.M / (double)(t.M - 1) : var;
+                t.running_var[c] = (float)((1.0 - t.momentum) * t.running_var[c] + t.momentum * unb);
+            }
+            if (t.nbt && c == 0) *t.nbt += 1;
+        }
+    }
+    __syncthreads();
+}
+
 __global__ void bn_eval_stats_kernel(int C, const float* gamma, const float* beta, const float* rm,
                                      const float* rv, float eps, float* stat) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,17 +230,25 @@ __global__ void bn_eval_stats_kernel(int C, const float* gamma, const float* bet
 
 // grid stride (gridDim*BLK) is a multiple of G = C/VEC (launcher guarantees it), so a thread's channel group is
 // fixed: per-channel coefficients are loaded into registers ONCE instead of per element
-template <typename T, int VEC>
+template <typename T, int VEC, bool TRAIN>
 __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, int ycs, int C, int64_t M, int64_t V,
-                                                       const float* __restrict__ stat, const float* __restrict__ drop,
+                                                       float* __restrict__ stat, BnPart tr, const float* __restrict__ drop,
                                                        T* __restrict__ z, int zcs) {
     int G = C / VEC;
     int64_t gtid = (int64_t)blockIdx.x * BLK + threadIdx.x;
     int g = (int)(gtid % G);
     int64_t row = gtid / G, rstep = ((int64_t)gridDim.x * BLK) / G;
     float a[VEC], b[VEC];
+    if constexpr (TRAIN) {
+        __shared__ double red[BLK * 4];
+        __shared__ float ab[2 * MAXC_BN];
+        bn_train_coeffs(tr, C, stat, ab, red);
 #pragma unroll
-    for (int i = 0; i < VEC; i++) { a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i]; }
+        for (int i = 0; i < VEC; i++) { a[i] = ab[g * VEC + i]; b[i] = ab[MAXC_BN + g * VEC + i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i]; }
+    }
     for (; row < M; row += rstep) {
         float v[VEC], o[VEC];
         ldv<T, VEC>(y + row * ycs + g * VEC, v);
@@ -179,12 +263,15 @@ __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
-// nred = blocks of the reduction proper (= gridDim.x unless a slab-sum job rides behind them, see bn_bwd)
+// nred = blocks of the reduction proper (= gridDim.x unless a slab-sum job rides behind them, see bn_bwd).
+// skp != NULL: dz arrives as the ks fp32 split-K partials of the input-gradient conv that produced it ([ks][M][C]); they
+// are summed and rounded HERE and dz is written for the apply pass -- the split-K finishing launch disappears
 template <typename T, int VEC>
 __device__ __forceinline__ void bn_bwd_reduce_body(int nred, const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
                                                    int ycs, int C, int64_t M, int64_t V,
                                                    const float* __restrict__ stat,
-                                                   const float* __restrict__ drop, float* __restrict__ part) {
+                                                   const float* __restrict__ drop, float* __restrict__ part,
+                                                   const float* __restrict__ skp = nullptr, int ks = 0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int r, g, R;
     bool active = row_map<VEC>(C, r, g, R);
@@ -201,7 +288,19 @@ __device__ __forceinline__ void bn_bwd_reduce_body(int nred, const T* __restrict
         for (int64_t row = (int64_t)blockIdx.x * R + r; row < M; row += (int64_t)nred * R) {
             float yv[VEC], gv[VEC];
             ldv<T, VEC>(y + row * ycs + g * VEC, yv);
-            ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
+            if (skp) {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) gv[i] = 0.f;
+                for (int k = 0; k < ks; k++) {
+                    const float* p = skp + ((int64_t)k * M + row) * C + g * VEC;
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) gv[i] += p[i];
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; i++) gv[i] = round_to<T>(gv[i]);
+                stv<T, VEC>(const_cast<T*>(dz) + row * dzcs + g * VEC, gv);
+            } else
+                ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
             const float* dr = drop ? drop + (int64_t)((unsigned)row / (unsigned)V) * C + g * VEC : nullptr;
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
@@ -220,16 +319,18 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(BLK) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
                                                             int ycs, int C, int64_t M, int64_t V,
                                                             const float* __restrict__ stat,
-                                                            const float* __restrict__ drop, float* __restrict__ part) {
-    bn_bwd_reduce_body<T, VEC>((int)gridDim.x, dz, dzcs, y, ycs, C, M, V, stat, drop, part);
+                                                            const float* __restrict__ drop, float* __restrict__ part,
+                                                            const float* __restrict__ skp, int ks) {
+    bn_bwd_reduce_body<T, VEC>((int)gridDim.x, dz, dzcs, y, ycs, C, M, V, stat, drop, part, skp, ks);
 }
 // the same with a pending weight-gradient slab sum in the blocks behind the reduction's: one chain link less
 template <typename T, int VEC>
 __global__ __launch_bounds__(BLK) void bn_bwd_reduce_slab_kernel(int nred, const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
                                                                  int ycs, int C, int64_t M, int64_t V,
                                                                  const float* __restrict__ stat,
-                                                                 const float* __restrict__ drop, float* __restrict__ part, SlabJob job) {
-    if ((int)blockIdx.x < nred) bn_bwd_reduce_body<T, VEC>(nred, dz, dzcs, y, ycs, C, M, V, stat, drop, part);
+                                                                 const float* __restrict__ drop, float* __restrict__ part, SlabJob job,
+                                                                 const float* __restrict__ skp, int ks) {
+    if ((int)blockIdx.x < nred) bn_bwd_reduce_body<T, VEC>(nred, dz, dzcs, y, ycs, C, M, V, stat, drop, part, skp, ks);
     else slab_job_run(job, (int)blockIdx.x - nred);
 }
 
@@ -261,25 +362,55 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
 
 // dy = g*(dyh - c1 - xhat*c2) rewritten per channel as  dy = g*dyh + A*y + B  with
 //   A = -g*c2*invstd,  B = g*(c2*invstd*mean - c1);  coefficients live in registers (fixed channel group per thread)
-template <typename T, int VEC>
+// SMALL: no finalize launch ran -- `coef` is the reduction's partial rows [nrows][2][C]; the prologue sums them (every
+// workgroup, fixed order, double) and workgroup 0 writes dgamma / dbeta (+)=
+template <typename T, int VEC, bool SMALL>
 __global__ __launch_bounds__(BLK) void bn_bwd_apply_kernel(const T* __restrict__ dz, int dzcs, const T* __restrict__ y,
                                                            int ycs, int C, int64_t M, int64_t V,
                                                            const float* __restrict__ stat, const float* __restrict__ coef,
+                                                           int nrows, float* dgamma, float* dbeta, int accumulate,
                                                            const float* __restrict__ drop, T* __restrict__ dy, int dycs) {
     int G = C / VEC;
     int64_t gtid = (int64_t)blockIdx.x * BLK + threadIdx.x;
     int g = (int)(gtid % G);
     int64_t row = gtid / G, rstep = ((int64_t)gridDim.x * BLK) / G;
     float a[VEC], b[VEC], gg[VEC], A[VEC], B[VEC];
+    if constexpr (SMALL) {
+        __shared__ double red[BLK * 4];
+        __shared__ float cf[2 * MAXC_BN];
+        double sq[2];
+        rows_sum(coef, nrows, C, red, sq);
+        if (threadIdx.x < C) {
+            int c = threadIdx.x;
+            cf[c] = (float)(sq[0] / (double)M);
+            cf[MAXC_BN + c] = (float)(sq[1] / (double)M);
+            if (blockIdx.x == 0) {
+                if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sq[1] : (float)sq[1];
+                if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sq[0] : (float)sq[0];
+            }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VEC; i++) {
-        int c = g * VEC + i;
-        float mean = stat[c], inv = stat[C + c];
-        a[i] = stat[2 * C + c]; b[i] = stat[3 * C + c];
-        gg[i] = coef[2 * C + c];
-        float k = gg[i] * coef[C + c] * inv;
-        A[i] = -k;
-        B[i] = k * mean - gg[i] * coef[c];
+        for (int i = 0; i < VEC; i++) {
+            int c = g * VEC + i;
+            float mean = stat[c], inv = stat[C + c];
+            a[i] = stat[2 * C + c]; b[i] = stat[3 * C + c];
+            gg[i] = a[i];
+            float k = gg[i] * cf[MAXC_BN + c] * inv;
+            A[i] = -k;
+            B[i] = k * mean - gg[i] * cf[c];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            int c = g * VEC + i;
+            float mean = stat[c], inv = stat[C + c];
+            a[i] = stat[2 * C + c]; b[i] = stat[3 * C + c];
+            gg[i] = coef[2 * C + c];
+            float k = gg[i] * coef[C + c] * inv;
+            A[i] = -k;
+            B[i] = k * mean - gg[i] * coef[c];
+        }
     }
     for (; row < M; row += rstep) {
         float yv[VEC], gv[VEC], o[VEC];
@@ -333,21 +464,40 @@ inline int stream_grid(int64_t total, int G) {
 
 size_t bn_ws_floats(int C) { return (size_t)MAXBLK * 2 * C + 3 * (size_t)C; }
 
+// "small" = a deep-level tensor whose reduction fits a few workgroups: <= SMALL_ROWS partial rows, finished by the consumer
+constexpr int64_t SMALL_ELEMS = 2 << 20;
+inline bool bn_small(int C, int64_t M) {
+    return C >= 4 && C <= MAXC_BN && (C & (C - 1)) == 0 && M * C <= SMALL_ELEMS && !getenv("MI3D_NO_SMALL_BN");
+}
+// number of partial rows for a small tensor: <= SMALL_ROWS, and rows*2*C a multiple of 1024 (rows_sum reads it as float4 x 256)
+inline int bn_small_rows(int nblk, int C) {
+    int unit = 512 / C < 1 ? 1 : 512 / C;
+    if (nblk > SMALL_ROWS) nblk = SMALL_ROWS;
+    nblk = nblk / unit * unit;
+    return nblk < unit ? unit : nblk;
+}
+
 int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* stat,
-                   float* ws, hipStream_t s) {
+                   float* ws, hipStream_t s, int* small_rows) {
     MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_train_stats: bad C=%d M=%lld", C, (long long)M);
+    bool small = small_rows && bn_small(C, M);
+    if (small_rows) *small_rows = 0;
     DISPATCH_T(dtype, T, {
         bool v8 = vec8_ok(C, ycs, ycs, y, y, sizeof(T));
         int G = v8 ? C / 8 : C, R = BLK / G;
         int nblk = reduce_grid(M, R);
+        if (small) nblk = bn_small_rows(nblk, C);
         size_t lds = (size_t)2 * R * C * sizeof(float);
         if (v8) bn_stats_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)y, ycs, C, M, ws);
         else bn_stats_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)y, ycs, C, M, ws);
         MI3D_LAUNCH_CHECK();
-        bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt,
-                                                 momentum, eps, stat);
-        MI3D_LAUNCH_CHECK();
+        if (small) *small_rows = nblk;
+        else {
+            bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt,
+                                                     momentum, eps, stat);
+            MI3D_LAUNCH_CHECK();
+        }
     });
     return 0;
 }
@@ -367,15 +517,24 @@ int bn_eval_stats(int C, const float* gamma, const float* beta, const float* rm,
     return 0;
 }
 
-int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* stat,
-                       const float* drop, void* z, int zcs, hipStream_t s) {
+int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, float* stat,
+                       const float* drop, void* z, int zcs, hipStream_t s, const BnSmall* small) {
     MI3D_CHECK_ARG(C >= 1 && M >= 1, "bn_apply: bad shape");
     MI3D_CHECK_ARG(!drop || M < (1ll << 32), "bn_apply: dropout path needs M < 2^32 (32-bit sample index)");
+    BnPart t{};
+    if (small) {
+        MI3D_CHECK_ARG(small->part && small->nrows >= 1 && small->nrows <= SMALL_ROWS && C <= MAXC_BN && small->gamma && small->beta,
+                       "bn_apply: bad partial statistics");
+        t = BnPart{small->part, small->nrows, M, small->gamma, small->beta, small->running_mean, small->running_var,
+                   small->num_batches_tracked, small->momentum, small->eps};
+    }
     DISPATCH_T(dtype, T, {
-        if (vec8_ok(C, ycs, zcs, y, z, sizeof(T)))
-            bn_apply_kernel<T, 8><<<stream_grid(M * (C / 8), C / 8), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
-        else
-            bn_apply_kernel<T, 1><<<stream_grid(M * C, C), BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, drop, (T*)z, zcs);
+        bool v8 = vec8_ok(C, ycs, zcs, y, z, sizeof(T));
+        int grid = v8 ? stream_grid(M * (C / 8), C / 8) : stream_grid(M * C, C);
+        if (v8 && small) bn_apply_kernel<T, 8, true><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
+        else if (v8) bn_apply_kernel<T, 8, false><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
+        else if (small) bn_apply_kernel<T, 1, true><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
+        else bn_apply_kernel<T, 1, false><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
         MI3D_LAUNCH_CHECK();
     });
     return 0;
@@ -383,29 +542,36 @@ int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int6
 
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta, int accumulate,
-           float* ws, hipStream_t s, const SlabJob* extra) {
+           float* ws, hipStream_t s, const SlabJob* extra, const float* skp, int ks) {
     MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_bwd: bad C=%d", C);
     MI3D_CHECK_ARG(!drop || M < (1ll << 32), "bn_bwd: dropout path needs M < 2^32 (32-bit sample index)");
     float* part = ws;
     float* coef = ws + (size_t)MAXBLK * 2 * C;
+    bool small = bn_small(C, M);
     DISPATCH_T(dtype, T, {
         bool v8 = vec8_ok(C, ycs, dzcs, y, dz, sizeof(T)) && dycs % 8 == 0 && ((uintptr_t)dy % 16 == 0);
+        MI3D_CHECK_ARG(!skp || (v8 && ks >= 1), "bn_bwd: split-K source needs the vector path");
         int G = v8 ? C / 8 : C, R = BLK / G;
         int nblk = reduce_grid(M, R);
+        if (small) nblk = bn_small_rows(nblk, C);
         size_t lds = (size_t)2 * R * C * sizeof(float);
         if (extra && extra->nblocks > 0) {
             int tot = nblk + extra->nblocks;
-            if (v8) bn_bwd_reduce_slab_kernel<T, 8><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra);
-            else bn_bwd_reduce_slab_kernel<T, 1><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra);
-        } else if (v8) bn_bwd_reduce_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
-        else bn_bwd_reduce_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part);
+            if (v8) bn_bwd_reduce_slab_kernel<T, 8><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra, skp, ks);
+            else bn_bwd_reduce_slab_kernel<T, 1><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra, nullptr, 0);
+        } else if (v8) bn_bwd_reduce_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, skp, ks);
+        else bn_bwd_reduce_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, nullptr, 0);
         MI3D_LAUNCH_CHECK();
-        bn_bwd_finalize_kernel<<<C, FIN_T, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);
-        MI3D_LAUNCH_CHECK();
-        if (v8)
-            bn_bwd_apply_kernel<T, 8><<<stream_grid(M * (C / 8), C / 8), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
-        else
-            bn_bwd_apply_kernel<T, 1><<<stream_grid(M * C, C), BLK, 0, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, coef, drop, (T*)dy, dycs);
+        if (!small) {
+            bn_bwd_finalize_kernel<<<C, FIN_T, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);
+            MI3D_LAUNCH_CHECK();
+        }
+        int grid = v8 ? stream_grid(M * (C / 8), C / 8) : stream_grid(M * C, C);
+        const T* dzp = (const T*)dz; const T* yp = (const T*)y; T* dyp = (T*)dy;
+        if (small && v8) bn_bwd_apply_kernel<T, 8, true><<<grid, BLK, 0, s>>>(dzp, dzcs, yp, ycs, C, M, V, stat, part, nblk, dgamma, dbeta, accumulate, drop, dyp, dycs);
+        else if (small) bn_bwd_apply_kernel<T, 1, true><<<grid, BLK, 0, s>>>(dzp, dzcs, yp, ycs, C, M, V, stat, part, nblk, dgamma, dbeta, accumulate, drop, dyp, dycs);
+        else if (v8) bn_bwd_apply_kernel<T, 8, false><<<grid, BLK, 0, s>>>(dzp, dzcs, yp, ycs, C, M, V, stat, coef, 0, nullptr, nullptr, 0, drop, dyp, dycs);
+        else bn_bwd_apply_kernel<T, 1, false><<<grid, BLK, 0, s>>>(dzp, dzcs, yp, ycs, C, M, V, stat, coef, 0, nullptr, nullptr, 0, drop, dyp, dycs);
         MI3D_LAUNCH_CHECK();
     });
     return 0;
@@ -413,15 +579,19 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
 
 int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, int ycs, int C, int64_t M, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
-                          float* stat, float* ws, hipStream_t s) {
+                          float* stat, float* ws, hipStream_t s, int* small_rows) {
     MI3D_CHECK_ARG(C % 8 == 0 && C / 8 <= BLK && ycs % 8 == 0 && ((uintptr_t)y % 16 == 0) && ks >= 1 && M >= 1,
                    "bn_train_stats_splitk: unsupported shape C=%d ycs=%d", C, ycs);
+    bool small = small_rows && bn_small(C, M);
+    if (small_rows) *small_rows = 0;
     int G = C / 8, R = BLK / G;
     int64_t want = (M + R - 1) / R;                 // one row per thread: the ks fp32 partial reads dominate, spread them wide
     int nblk = (int)(want > MAXBLK ? MAXBLK : want);
+    if (small) nblk = bn_small_rows(nblk, C);
     size_t lds = (size_t)2 * R * C * sizeof(float);
     bn_stats_splitk_kernel<<<nblk, BLK, lds, s>>>(skp, ks, bias, (bf16*)y, ycs, C, M, ws);
     MI3D_LAUNCH_CHECK();
+    if (small) { *small_rows = nblk; return 0; }
     bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
     MI3D_LAUNCH_CHECK();
     return 0;

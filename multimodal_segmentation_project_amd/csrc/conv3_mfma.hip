@@ -1439,7 +1439,8 @@ bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo
 
 int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                          int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats, float* skws,
-                         hipStream_t s, SlabJob* pend) {
+                         hipStream_t s, SlabJob* pend, int* ks_deferred) {
+    if (ks_deferred) *ks_deferred = 0;
     MI3D_CHECK_ARG(conv3_mfma_bwd_fused_ok(Cin, Cout, xcs, dycs, dxcs, g) && dx && ((uintptr_t)dx % 16) == 0 && skws,
                    "conv3_mfma_bwd_fused: unsupported layer %d->%d", Cin, Cout);
     WgCfg c = wgrad_cfg(Cin, Cout, g);
@@ -1465,6 +1466,11 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     else if (ks > 1) conv3_bwd_fused_kernel<false, true><<<nblk, BLK, lds, s>>>(a);
     else conv3_bwd_fused_kernel<false, false><<<nblk, BLK, lds, s>>>(a);
     MI3D_LAUNCH_CHECK();
+    if (ks > 1 && ks_deferred) {
+        // the consumer of dx (the BatchNorm-backward reduction of the layer below) sums the split-K partials itself
+        *ks_deferred = ks;
+        return wgrad_slab_sum(wgws, c.nsb, Cin, Cout, dW, db, accumulate, s, pend);
+    }
     if (ks > 1 && !getenv("MI3D_NO_BWD_TAIL")) {
         int64_t tot = g.M() * (Cin / 8);
         TailArgs t;

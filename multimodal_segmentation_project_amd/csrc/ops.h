@@ -67,7 +67,9 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
 bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g);
 int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                          int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats, float* skws,
-                         hipStream_t s, SlabJob* pend = nullptr);
+                         hipStream_t s, SlabJob* pend = nullptr, int* ks_deferred = nullptr);
+// ks_deferred != NULL: a split-K input gradient is LEFT as fp32 partials in skws ([ks][M][Cin], *ks_deferred = ks, dx not
+// written) for bn_bwd(..., skp, ks) of the layer below to finish inside its reduction; 0 = dx was written as usual
 bool conv3_mfma_bwd_fused_persist_ok(int Cin, int Cout, int xcs, int dycs, Geo g);
 int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                                  int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats,
@@ -83,9 +85,17 @@ int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo 
 // Reference: nn.BatchNorm3d / nn.ReLU(inplace) / nn.Dropout3d  models/unet.py:12-14,16-18.
 // stat buffer layout: float[4][C] = {mean, invstd, a = gamma*invstd, b = beta - mean*a}
 size_t bn_ws_floats(int C);
+// small_rows != NULL and the tensor is small (deep levels): NO finalize launch -- *small_rows = number of partial rows left
+// in ws (<= 128) and the caller hands them to bn_apply_relu_drop (BnSmall), which finishes them in its prologue;
+// otherwise *small_rows = 0 and stat / the running statistics are final on return as before
 int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                   float eps, float* stat, float* ws, hipStream_t s);
+                   float eps, float* stat, float* ws, hipStream_t s, int* small_rows = nullptr);
+struct BnSmall {
+    const float* part; int nrows;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    float momentum, eps;
+};
 // same finalize, fed by conv-epilogue partials part[nblk][2][C]
 int bn_train_finalize(const float* part, int nblk, int C, int64_t M, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
@@ -101,19 +111,23 @@ constexpr int MAX_FOLD_JOBS = 2 * (2 * 6 + 1);
 struct BnFoldJobs { int n; float eps; BnFoldJob j[MAX_FOLD_JOBS]; };
 int bn_fold_all(const BnFoldJobs& J, hipStream_t s);
 // z = drop[n,c] * relu(a*y + b)      (drop == NULL -> 1)
-int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, const float* stat,
-                       const float* drop, void* z, int zcs, hipStream_t s);
+// small != NULL: batch statistics from small->part (prologue); stat[4][C] is then WRITTEN (kept for backward) and the
+// running statistics / num_batches_tracked are updated here
+int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, float* stat,
+                       const float* drop, void* z, int zcs, hipStream_t s, const BnSmall* small = nullptr);
 // dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)), dyh = dz*drop*[a*y+b > 0]; dgamma, dbeta (+)=
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
-           int accumulate, float* ws, hipStream_t s, const SlabJob* extra = nullptr);
+           int accumulate, float* ws, hipStream_t s, const SlabJob* extra = nullptr, const float* skp = nullptr, int ks = 0);
+// skp != NULL: dz is still the ks fp32 split-K partials [ks][M][C] of the conv that produced it; the reduction sums and
+// rounds them and WRITES dz (the split-K finishing launch of that conv is skipped by the caller)
 // extra: a pending slab sum that rides in the reduction kernel's launch (extra blocks)
 int slab_job_launch(const SlabJob& q, hipStream_t s);
 
 // split-K conv finish (y = bf16(bias + sum_k skp[k][M][C])) fused with the batch statistics of the stored values
 int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, int ycs, int C, int64_t M, const float* gamma,
                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                          float momentum, float eps, float* stat, float* ws, hipStream_t s);
+                          float momentum, float eps, float* stat, float* ws, hipStream_t s, int* small_rows = nullptr);
 
 // ---- MaxPool3d(2,2) ------------------------------------------------------------------------ pool.hip
 // Reference: models/unet.py:40,71.  g = INPUT geometry; odd sides floor like nn.MaxPool3d (last slice in no window).

@@ -271,22 +271,24 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             MI3D_TRY(conv3_direct_fwd(idt, p.dt, in, ics, H.Cin, c.at<float>(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout,
                                       H.Cout, g, c.s));
         }
+        int small_rows = 0;      // deep levels: the statistics' few partial rows are finished by the apply kernel (no finalize launch)
         if (fused_stats) {
             MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
                                        c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.s));
         } else if (training && ksd > 0) {
             MI3D_TRY(bn_train_stats_splitk(c.at<float>(p.skws), ksd, c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2),
                                            c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat),
-                                           c.at<float>(p.bnws), c.s));
+                                           c.at<float>(p.bnws), c.s, &small_rows));
         } else if (training) {
             MI3D_TRY(bn_train_stats(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt,
-                                    p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.at<float>(p.bnws), c.s));
+                                    p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.at<float>(p.bnws), c.s, &small_rows));
         } else {
             MI3D_CHECK_ARG(rm && rv, "eval-mode forward needs running statistics");
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
+        BnSmall sm{c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps};
         MI3D_TRY(bn_apply_relu_drop(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
-                                    (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, c.s));
+                                    (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, c.s, small_rows > 0 ? &sm : nullptr));
     }
     return 0;
 }
@@ -302,6 +304,8 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
     auto G = [&](int i) { return grads ? (float*)grads[i] : nullptr; };
     // measured (96^3, hipGraph): any second stream in the captured graph costs ~130 us/step more than it hides -> off by default
     bool two = c.s2 != nullptr && c.ev != nullptr;
+    const float* dz_skp = nullptr;      // dz of half 0 left as split-K partials by half 1's fused backward launch
+    int dz_ks = 0;
     for (int h = 1; h >= 0; h--) {
         const HalfP& H = B.h[h];
         int k = c.seq++;
@@ -311,7 +315,7 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         int dcs = h == 1 ? dzcs : H.Cout;
         MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
                         drop ? drop + H.drop_off : nullptr, dyb, H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
-                        c.at<float>(p.bnws), c.s, c.has_pend ? &c.pend : nullptr));
+                        c.at<float>(p.bnws), c.s, c.has_pend ? &c.pend : nullptr, h == 0 ? dz_skp : nullptr, h == 0 ? dz_ks : 0));
         c.has_pend = false;
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
@@ -328,9 +332,15 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && !(h == 0 && b > p.L && p.planar[B.level]) &&
             conv3_mfma_bwd_fused_ok(H.Cin, H.Cout, ics, H.Cout, dxs_f, g)) {
             SlabJob* ps = c.pend_slot();
+            // half 1's input gradient feeds straight into half 0's BatchNorm-backward reduction: leave a split-K result as
+            // partials and let that reduction finish it (one launch less on the chain)
+            bool defer = h == 1 && ps && dxs_f % 8 == 0 && !getenv("MI3D_NO_DEFER_TAIL");
+            int ksd = 0;
             MI3D_TRY(conv3_mfma_bwd_fused(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx), G(H.pidx + 1),
-                                          accumulate, c.at<float>(p.wgws), p.wgws_floats, c.at<float>(p.skws), c.s, ps));
+                                          accumulate, c.at<float>(p.wgws), p.wgws_floats, c.at<float>(p.skws), c.s, ps,
+                                          defer ? &ksd : nullptr));
             c.pend_filled();
+            if (ksd > 0) { dz_skp = c.at<float>(p.skws); dz_ks = ksd; }
             continue;
         }
         if (G(H.pidx) || G(H.pidx + 1)) {
