@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3 --pmc passes)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N=1 only: create a 1-rank RCCL group and drive the DP bucket path (side stream, all-reduces, segmented graphs)")
     ap.add_argument("--workload", default="train", choices=["train", "distill", "dann", "eval"],
                     help="train = the headline metric (BASELINE config 2/3); distill = config 5 step (student + frozen teacher); "
                          "dann = config 4 step (N source + N target volumes per GPU); eval = inference forward + loss + metrics")
@@ -143,6 +145,12 @@ def main():
     if world > 1:
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif a.force_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        os.environ["MI3D_FORCE_COMM"] = "1"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -211,7 +219,8 @@ def main():
             "config": {"workload": (f"UNet3D(1->4, features 16/32/64/128) {a.size}^3 patch, per-GPU batch {a.batch}, "
                                     f"fwd + Dice/CE loss + bwd + AdamW + metrics, dropout {a.dropout}") if a.workload == "train"
                        else f"{a.workload} step, UNet3D {a.size}^3, per-GPU batch {a.batch}",
-                       "global_batch": global_batch, "parallelism": f"dp{world}", "hipgraph": bool(ts.use_graph)},
+                       "global_batch": global_batch, "parallelism": f"dp{world}", "hipgraph": bool(ts.use_graph),
+                       "comm_path": bool(ts.do_comm)},
             "final_step": {"loss": met[0], "iou": met[1], "dice": met[2], "acc": met[3]},
             "step_hbm_frac": algo_gb_step / (ms * 1e-3) / HBM_PEAK_GBS,
             "step_algorithmic_gb": algo_gb_step,
@@ -221,7 +230,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.size, a.batch)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or a.force_comm:
         dist.destroy_process_group()
 
 
