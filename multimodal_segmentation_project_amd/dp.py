@@ -4,9 +4,9 @@ Replaces what accelerate/DDP does for the reference: C1 parameter
 C2 gradient averaging, C3 BatchNorm-buffer authority of rank 0, C4 metric averaging — re-designed for a fully
 connected xGMI node instead of translated from DDP's bucket machinery:
   * gradients live in ONE flat fp32 arena; a "bucket" is a contiguous arena range, reduced in place;
-  * four buckets keyed by the backward segment that completes them, ordered by readiness:
-      [upconvs+decoder+final] after the decoder, [bottleneck], [encoder.L-1], [encoder.0..L-2] at the end,
-    so 82 % of the gradient bytes are in flight while the bandwidth-heavy full-resolution encoder backward runs;
+  * two buckets keyed by the backward segment that completes them: [encoder.L-1 .. final_conv] (97 % of the bytes) after
+    encoder.L-1's backward, in flight while the bandwidth-heavy encoder.L-2..0 backward runs; [encoder.0..L-2] at the end
+    (four readiness-ordered buckets are available as fine_buckets=True; fewer collective calls measured faster);
   * BatchNorm statistics stay per-rank (DDP + BatchNorm3d semantics, NOT SyncBN).
 """
 import torch
@@ -45,11 +45,21 @@ class ParamArena:
         return self.offsets[first], end
 
 
-def bucket_ranges(arena, n_levels):
+def bucket_ranges(arena, n_levels, fine=False):
     """{backward segment index -> (lo, hi) arena range complete after that segment}.  Parameter table order is the
-    reference's parameters() order: encoder.0..L-1, bottleneck, upconvs, decoder, final_conv (include/mi3d.h)."""
+    reference's parameters() order: encoder.0..L-1, bottleneck, upconvs, decoder, final_conv (include/mi3d.h).
+
+    Default: TWO exchanges.  [encoder.L-1, bottleneck, upconvs, decoder, final_conv] (one contiguous range, 97 % of the
+    bytes for the default net) goes out after encoder.L-1's backward segment, while the bandwidth-heavy encoder.L-2..0
+    backward (0.45 ms at 96^3) still runs; [encoder.0..L-2] at the end.  Every collective call costs ~25 us of HOST time
+    in an eagerly launched step (measured: 5 calls = +0.12 ms/step on the 1-rank RCCL path), so fewer, larger exchanges win
+    over the finest readiness order (fine=True: four buckets after decoder / bottleneck / encoder.L-1 / the end)."""
     L = n_levels
     npar = len(arena.params)
+    if not fine:
+        if L > 1:
+            return {L + 2: arena.range_of(8 * (L - 1), npar), 2 * L + 1: arena.range_of(0, 8 * (L - 1))}
+        return {2 * L + 1: arena.range_of(0, npar)}
     buckets = {L: arena.range_of(8 * (L + 1), npar),            # upconvs + decoder + final_conv
                L + 1: arena.range_of(8 * L, 8 * L + 8)}         # bottleneck
     if L > 1:
@@ -61,12 +71,12 @@ def bucket_ranges(arena, n_levels):
 
 
 class DataParallelComm:
-    def __init__(self, arena, n_levels, group=None, force=False):
+    def __init__(self, arena, n_levels, group=None, force=False, fine_buckets=False):
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         # force: issue the collectives even in a 1-rank group (MI3D_FORCE_COMM: the RCCL path on a 1-GPU box)
         self.enabled = self.world > 1 or (bool(force) and dist.is_available() and dist.is_initialized())
-        self.buckets = bucket_ranges(arena, n_levels)
+        self.buckets = bucket_ranges(arena, n_levels, fine=fine_buckets)
         self.backend = dist.get_backend(group) if self.enabled else None
 
     def broadcast_parameters(self, buffers=()):

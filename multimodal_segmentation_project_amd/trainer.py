@@ -100,7 +100,8 @@ class _StepBase:
         # at world 1 -- a 1-rank RCCL group on the 1-GPU box exercises the real code path
         self.force_comm = bool(force_comm) or os.environ.get("MI3D_FORCE_COMM", "0") == "1"
         self.do_comm = self.world > 1 or (self.force_comm and dist.is_available() and dist.is_initialized())
-        self.comm = DataParallelComm(self.arena, n_levels, process_group, force=self.do_comm)
+        self.comm = DataParallelComm(self.arena, n_levels, process_group, force=self.do_comm,
+                                     fine_buckets=os.environ.get("MI3D_FINE_BUCKETS", "0") == "1")
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.do_comm else None
         self.use_graph = bool(use_graph)
         self._statics = {}
@@ -425,10 +426,10 @@ class TrainStep(_StepBase):
         call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, desc.D, v,
              C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
              ptr(st["met_ws"]), s)
-        if self.do_comm:
-            # the four scalar gathers fused into one 4-float all-reduce, in flight under the whole backward
-            met = st["metrics"]
-            comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
+        # the four scalar gathers fused into one 4-float all-reduce; it rides on the first gradient exchange
+        # point (one fork of the comm stream less) and is in flight under the rest of the backward
+        met = st["metrics"]
+        met_pending = self.do_comm
         if run_backward:
             call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
                  ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
@@ -447,7 +448,11 @@ class TrainStep(_StepBase):
                          self._events)
                     start = seg + 1
                     if exch:
-                        comm(lambda b=tuple(exch): self._on_comm_stream(lambda: [self.comm.reduce_bucket(k) for k in b]))
+                        with_met, met_pending = met_pending, False
+                        comm(lambda b=tuple(exch), wm=with_met: self._on_comm_stream(
+                            lambda: ([self.comm.average_(met)] if wm else []) + [self.comm.reduce_bucket(k) for k in b]))
+        if met_pending:
+            comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
         if self.do_comm:
             comm(self._join_comm)
         if boundary:

@@ -83,16 +83,23 @@ def test_dp_world2_gloo():
 
 
 def test_bucket_order_matches_backward_readiness():
-    """Default net: the first bucket (ready after the decoder) + bottleneck + encoder.3 carry > 80 % of the bytes."""
+    """Default net.  Two exchanges by default: encoder.3 .. final_conv (>= 95 % of the bytes) is complete after encoder.3's
+    backward segment; fine=True keeps the four readiness-ordered buckets (decoder, bottleneck, encoder.3 carry > 80 %)."""
     m = mi.UNet3D(in_channels=1, out_channels=4)
     arena = ParamArena(m.parameters(), "cpu")
-    b = bucket_ranges(arena, 4)
+    names = [k for k, _ in m.named_parameters()]
+    b2 = bucket_ranges(arena, 4)
+    assert sorted(b2) == [6, 9]
+    assert sum(hi - lo for lo, hi in b2.values()) == arena.numel
+    lo, hi = b2[6]
+    first = [n for n, o in zip(names, arena.offsets) if lo <= o < hi]
+    assert first[0].startswith("encoder.3") and first[-1] == "final_conv.bias" and (hi - lo) / arena.numel > 0.95
+    b = bucket_ranges(arena, 4, fine=True)
     assert sorted(b) == [4, 5, 6, 9]
     sizes = {k: hi - lo for k, (lo, hi) in b.items()}
     assert sum(sizes.values()) == arena.numel
     early = sizes[4] + sizes[5] + sizes[6]
     assert early / arena.numel > 0.8
-    names = [k for k, _ in m.named_parameters()]
     lo, hi = b[4]
     first = [n for n, o in zip(names, arena.offsets) if lo <= o < hi]
     assert first[0].startswith("upconvs.0") and first[-1] == "final_conv.bias"

@@ -382,7 +382,7 @@ def _nccl1_worker(port, q):
         base = outs["plain"]
         for name, o in outs.items():
             assert torch.equal(o[0], base[0]) and torch.equal(o[1], base[1]), name
-        assert outs["graph"][2] == 1 and outs["comm_graph"][2] >= 6          # comm-free runs of kernels between all-reduces
+        assert outs["graph"][2] == 1 and outs["comm_graph"][2] >= 3          # comm-free runs of kernels between all-reduces
         # DANN under forced communication (discriminator arena = the fifth bucket)
         douts = []
         for kw in ({}, dict(force_comm=True, use_graph=True)):
