@@ -105,11 +105,17 @@ def roofline_dominant(size, batch, dtype_code, iters=10):
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     # HBM traffic per launch from the committed PMC passes of this same loop (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate runs of `bench.py --roofline-only`, corrected by tools/pmc_traffic.py); null if the file is absent
+    # (a PMC pass cannot run inside this process; the committed value is only reported while the kernel still takes the time
+    # it took when the counters were collected: a changed kernel yields null instead of a stale number)
     traffic = None
     tf = os.path.join(ROOT, "profiles", "roofline_kernel_traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get(f"{size}^3xN{batch}_{'bf16' if dtype_code == 1 else 'fp32'}")
+            rec = json.load(open(tf))
+            traffic = rec.get(f"{size}^3xN{batch}_{'bf16' if dtype_code == 1 else 'fp32'}")
+            ref_ms = rec.get("_ms_per_launch_when_measured")
+            if traffic is not None and ref_ms and abs(ms - ref_ms) > 0.10 * ref_ms:
+                traffic = None
         except Exception:   # noqa: BLE001
             traffic = None
     return {"bound": "hbm", "kernel": "conv3 fwd 32->16 (decoder.3.conv0)", "achieved": achieved, "peak": HBM_PEAK_GBS,
