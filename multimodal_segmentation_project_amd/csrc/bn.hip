@@ -153,13 +153,12 @@ struct BnPart {
     const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt;
     float momentum, eps;
 };
-// sum the nrows partial rows [nrows][2][C] per (k, channel): out[k] for threads < C.  Requirements (bn_small_rows):
-// C in {4..256} a power of two, nrows*2*C a multiple of 1024.  The flat array is read as float4, thread t taking elements
-// 4t + 1024 j: its (k, channel quad) is the same for every j, all loads are independent and unconditional (a scalar
-// `acc += part[r]` loop pays an L2 round trip per row: measured 0.3 us each), the per-thread sums are combined through
-// LDS in a fixed order.
+// sum the nrows partial rows [nrows][2][C] per (k, channel): out[k] for threads < C.  Requirement: C in {4..256} a power
+// of two.  The flat array is read as float4, thread t taking elements 4t + 1024 j: its (k, channel quad) is the same for
+// every j, the loads are independent (a scalar `acc += part[r]` loop pays an L2 round trip per row: measured 0.3 us each;
+// only the last, partial 1024-element block is guarded), the per-thread sums are combined through LDS in a fixed order.
 __device__ __forceinline__ void rows_sum(const float* __restrict__ part, int nrows, int C, double* red /* [BLK*4] */, double (&out)[2]) {
-    int J = (nrows * 2 * C) >> 10;
+    int total4 = (nrows * 2 * C) >> 2, J = total4 >> 8;
     const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + threadIdx.x;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     int j = 0;
@@ -172,6 +171,10 @@ __device__ __forceinline__ void rows_sum(const float* __restrict__ part, int nro
     }
     for (; j < J; j++) {
         f32x4 v = p4[(size_t)j * BLK];
+        acc[0] += (double)v[0]; acc[1] += (double)v[1]; acc[2] += (double)v[2]; acc[3] += (double)v[3];
+    }
+    if (J * BLK + (int)threadIdx.x < total4) {
+        f32x4 v = p4[(size_t)J * BLK];
         acc[0] += (double)v[0]; acc[1] += (double)v[1]; acc[2] += (double)v[2]; acc[3] += (double)v[3];
     }
 #pragma unroll
@@ -469,13 +472,9 @@ constexpr int64_t SMALL_ELEMS = 2 << 20;
 inline bool bn_small(int C, int64_t M) {
     return C >= 4 && C <= MAXC_BN && (C & (C - 1)) == 0 && M * C <= SMALL_ELEMS && !getenv("MI3D_NO_SMALL_BN");
 }
-// number of partial rows for a small tensor: <= SMALL_ROWS, and rows*2*C a multiple of 1024 (rows_sum reads it as float4 x 256)
-inline int bn_small_rows(int nblk, int C) {
-    int unit = 512 / C < 1 ? 1 : 512 / C;
-    if (nblk > SMALL_ROWS) nblk = SMALL_ROWS;
-    nblk = nblk / unit * unit;
-    return nblk < unit ? unit : nblk;
-}
+// number of partial rows for a small tensor
+inline int bn_small_rows(int nblk, int C) { return nblk > SMALL_ROWS ? SMALL_ROWS : nblk; }
+bool bn_small_ok(int C, int64_t M, int rows) { return bn_small(C, M) && rows >= 1 && rows <= SMALL_ROWS; }
 
 int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* stat,

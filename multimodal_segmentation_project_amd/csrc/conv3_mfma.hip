@@ -703,7 +703,8 @@ inline int pick_ksplit(int Cin, int Cout, Geo g) {
     if (big_geo(g)) return 1;
     int64_t wgs = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 8) * (Cout / (Cout % 32 == 0 ? 32 : 16));
     int nchunk = Cin / 16, k = 1;
-    while (wgs * k < 256 && k * 2 <= nchunk && nchunk % (k * 2) == 0 && k < 16) k *= 2;
+    static const int target = getenv("MI3D_KS_TARGET") ? atoi(getenv("MI3D_KS_TARGET")) : 256;
+    while (wgs * k < target && k * 2 <= nchunk && nchunk % (k * 2) == 0 && k < 16) k *= 2;
     return k;
 }
 

@@ -91,6 +91,7 @@ size_t bn_ws_floats(int C);
 int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                    float eps, float* stat, float* ws, hipStream_t s, int* small_rows = nullptr);
+bool bn_small_ok(int C, int64_t M, int rows);       // a producer's `rows` partial rows can take the consumer-prologue route
 struct BnSmall {
     const float* part; int nrows;
     const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* num_batches_tracked;

@@ -249,17 +249,25 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         float* rm = buffers ? (float*)buffers[H.bidx] : nullptr;
         float* rv = buffers ? (float*)buffers[H.bidx + 1] : nullptr;
         int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
-        bool fused_stats = false;
+        bool fused_stats = false, nosplit = false;
+        int nosplit_rows = 0;
         void* zo = h == 0 ? c.at(B.z1) : zout;
         int zocs = h == 0 ? H.Cout : zcs;
         int ksd = 0, c1_blocks = 0;
         if (H.mfma) {
             if (!c.packed) MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
             // training: a split-K launch leaves its finishing pass to the statistics kernel (ksd = split factor)
+            // deep levels in training: no split-K when the tile grid alone leaves few enough statistic rows for the apply
+            // kernel to finish (conv with fused partial sums -> apply: two launches instead of conv, split-K finish +
+            // statistics, apply)
+            int nsb = conv3_mfma_stat_blocks(H.Cin, H.Cout, g);
+            nosplit = training && !conv3_mfma_fuses_stats(H.Cin, H.Cout, g) && bn_small_ok(H.Cout, g.M(), nsb) &&
+                      getenv("MI3D_FWD_NOSPLIT");
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
-                                    training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
+                                    training ? c.at<float>(p.statpart) : nullptr, nosplit ? nullptr : c.at<float>(p.skws), c.s,
                                     (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr));
-            fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
+            fused_stats = training && (nosplit || conv3_mfma_fuses_stats(H.Cin, H.Cout, g));
+            if (nosplit) nosplit_rows = nsb;
         } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT") &&
                    !getenv("MI3D_NO_C1_MFMA")) {
             // first layer on the matrix cores (taps are the K dimension), BN partial sums fused like the other convs
@@ -272,7 +280,8 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
                                       H.Cout, g, c.s));
         }
         int small_rows = 0;      // deep levels: the statistics' few partial rows are finished by the apply kernel (no finalize launch)
-        if (fused_stats) {
+        if (nosplit) small_rows = nosplit_rows;
+        else if (fused_stats) {
             MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
                                        c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.s));
         } else if (training && ksd > 0) {
@@ -286,7 +295,7 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             MI3D_CHECK_ARG(rm && rv, "eval-mode forward needs running statistics");
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
-        BnSmall sm{c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps};
+        BnSmall sm{nosplit ? c.at<float>(p.statpart) : c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps};
         MI3D_TRY(bn_apply_relu_drop(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
                                     (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, c.s, small_rows > 0 ? &sm : nullptr));
     }
