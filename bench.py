@@ -241,7 +241,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.size, a.batch)
         print(json.dumps(res))
+    sys.stdout.flush()
     if world > 1 or a.force_comm:
+        dist.barrier()               # rank 0 may still be measuring its roofline kernel: leave together
         dist.destroy_process_group()
 
 
