@@ -231,6 +231,27 @@ __global__ void bn_eval_stats_kernel(int C, const float* gamma, const float* bet
     stat[3 * C + c] = (float)((double)beta[c] - (double)rm[c] * (double)gamma[c] * inv);
 }
 
+// Dropout3d scale of this thread's channel group for the sample `row` lies in: rows are visited in increasing order, so the
+// VEC scales are (re)loaded only when a sample boundary is crossed (a per-row `drop[(row / V) * C + c]` costs a 32-bit
+// division and VEC global loads per element: +0.14 ms/step at p = 0.1)
+template <int VEC>
+struct DropCache {
+    float s[VEC];
+    int64_t bound = 0;
+    __device__ __forceinline__ DropCache() {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) s[i] = 1.f;
+    }
+    __device__ __forceinline__ void at(const float* __restrict__ drop, int64_t row, int64_t V, int C, int c0) {
+        if (drop && row >= bound) {
+            int64_t n = (int64_t)((unsigned)row / (unsigned)V);
+            bound = (n + 1) * V;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) s[i] = drop[n * C + c0 + i];
+        }
+    }
+};
+
 // grid stride (gridDim*BLK) is a multiple of G = C/VEC (launcher guarantees it), so a thread's channel group is
 // fixed: per-channel coefficients are loaded into registers ONCE instead of per element
 template <typename T, int VEC, bool TRAIN>
@@ -252,15 +273,16 @@ __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
         for (int i = 0; i < VEC; i++) { a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i]; }
     }
+    DropCache<VEC> dc;
     for (; row < M; row += rstep) {
         float v[VEC], o[VEC];
         ldv<T, VEC>(y + row * ycs + g * VEC, v);
-        const float* dr = drop ? drop + (int64_t)((unsigned)row / (unsigned)V) * C + g * VEC : nullptr;
+        dc.at(drop, row, V, C, g * VEC);
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
             float t = fmaf(v[i], a[i], b[i]);
             t = t > 0.f ? t : 0.f;
-            o[i] = dr ? t * dr[i] : t;
+            o[i] = t * dc.s[i];
         }
         stv<T, VEC>(z + row * zcs + g * VEC, o);
     }
@@ -288,6 +310,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(int nred, const T* __restrict
             mean[i] = stat[g * VEC + i]; inv[i] = stat[C + g * VEC + i];
             a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i];
         }
+        DropCache<VEC> dc;
         for (int64_t row = (int64_t)blockIdx.x * R + r; row < M; row += (int64_t)nred * R) {
             float yv[VEC], gv[VEC];
             ldv<T, VEC>(y + row * ycs + g * VEC, yv);
@@ -304,11 +327,11 @@ __device__ __forceinline__ void bn_bwd_reduce_body(int nred, const T* __restrict
                 stv<T, VEC>(const_cast<T*>(dz) + row * dzcs + g * VEC, gv);
             } else
                 ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
-            const float* dr = drop ? drop + (int64_t)((unsigned)row / (unsigned)V) * C + g * VEC : nullptr;
+            dc.at(drop, row, V, C, g * VEC);
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
                 float pre = fmaf(yv[i], a[i], b[i]);
-                float m = pre > 0.f ? (dr ? dr[i] : 1.f) : 0.f;
+                float m = pre > 0.f ? dc.s[i] : 0.f;
                 float dyh = gv[i] * m;
                 acc[0][i] += dyh;
                 acc[1][i] += dyh * (yv[i] - mean[i]) * inv[i];
@@ -415,15 +438,16 @@ __global__ __launch_bounds__(BLK) void bn_bwd_apply_kernel(const T* __restrict__
             B[i] = k * mean - gg[i] * coef[c];
         }
     }
+    DropCache<VEC> dc;
     for (; row < M; row += rstep) {
         float yv[VEC], gv[VEC], o[VEC];
         ldv<T, VEC>(y + row * ycs + g * VEC, yv);
         ldv<T, VEC>(dz + row * dzcs + g * VEC, gv);
-        const float* dr = drop ? drop + (int64_t)((unsigned)row / (unsigned)V) * C + g * VEC : nullptr;
+        dc.at(drop, row, V, C, g * VEC);
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
             float pre = fmaf(yv[i], a[i], b[i]);
-            float m = pre > 0.f ? (dr ? dr[i] : 1.f) : 0.f;
+            float m = pre > 0.f ? dc.s[i] : 0.f;
             o[i] = fmaf(gg[i] * m, gv[i], fmaf(A[i], yv[i], B[i]));
         }
         stv<T, VEC>(dy + row * dycs + g * VEC, o);
