@@ -61,7 +61,7 @@ def _worker(rank, world, port, q):
             assert p.grad.data_ptr() >= arena.g.data_ptr()
         met = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1)
         comm.average_(met)
-        assert torch.allclose(met, torch.tensor([1.0, 2.0, 3.0, 4.0]) * 1.5)
+        assert torch.allclose(met, torch.tensor([1.0, 2.0, 3.0, 4.0]) * (world + 1) / 2)
         q.put((rank, "ok"))
     except Exception as e:      # noqa: BLE001
         q.put((rank, repr(e)))
@@ -69,17 +69,18 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_dp_world2_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_dp_world_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
 def test_bucket_order_matches_backward_readiness():
