@@ -917,3 +917,32 @@ def test_preprocessing_mri_at_scale_vs_oracle():
         assert got.min() == 0.0 and abs(got.max() - 1.0) < 1e-6
     ct = rng.normal(40.0, 250.0, (64, 64, 64)).astype(np.float32)
     np.testing.assert_allclose(P.preprocess_ct(t(ct)).cpu().numpy(), preproc_ref.preprocess_ct(ct), rtol=0, atol=1e-7)
+
+
+def test_encoder_freezing_like_the_reference(golden):
+    """train_unet.py:31-50,413-431 executed by the reference (fixture loops.npz freeze/*): freeze_encoder +
+    update_optimizer_for_frozen_encoder (AdamW over the trainable parameters only), two steps; then unfreeze_encoder + a
+    fresh AdamW over everything, one step.  Here: requires_grad flags + TrainStep / reset_optimizer()."""
+    g = golden("loops")
+    model = default_model().to(DEV).train()
+    for p in model.encoder.parameters():
+        p.requires_grad = False
+    ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=torch.float32)
+    batches = [synth(2, 32, 900 + i, blocky=True) for i in range(3)]
+    enc0 = {k: v.detach().clone() for k, v in model.encoder.state_dict().items() if "running" not in k and "num_batches" not in k}
+    outs = [ts.step(x.to(DEV), y.to(DEV)).cpu().clone() for x, y in batches[:2]]
+    np.testing.assert_allclose(torch.stack(outs).mean(0).numpy(), g["freeze/result_frozen"], rtol=3e-4)
+    for k, v in model.encoder.state_dict().items():
+        if k in enc0:
+            assert torch.equal(v, enc0[k]), k                          # frozen: no update, no weight decay
+    keys, dig = _digest(model.state_dict())
+    sel = np.array([k.endswith(".weight") for k in keys])
+    np.testing.assert_allclose(dig[sel, 1], g["freeze/param_digest_frozen"][sel, 1], rtol=1e-4)
+    for p in model.encoder.parameters():
+        p.requires_grad = True
+    ts.reset_optimizer()
+    out = ts.step(batches[2][0].to(DEV), batches[2][1].to(DEV)).cpu()
+    np.testing.assert_allclose(out.numpy(), g["freeze/result_unfrozen"], rtol=1e-3)      # argmax metrics after two AdamW steps
+    keys, dig = _digest(model.state_dict())
+    np.testing.assert_allclose(dig[sel, 1], g["freeze/param_digest_unfrozen"][sel, 1], rtol=1e-4)
+    assert int(ts.arena.step.item()) == 1

@@ -774,6 +774,28 @@ def gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, out):
     d["dann/seg_param_digest_after"] = dig
     _, dig = param_digest(disc.state_dict())
     d["dann/disc_param_digest_after"] = dig
+    # encoder freezing exactly as train_unet.py:31-50,413-431 does it: freeze_encoder + update_optimizer_for_frozen_encoder,
+    # two steps; then unfreeze_encoder + a fresh AdamW over all parameters, one step
+    accf = Accelerator(gradient_accumulation_steps=1, cpu=True)
+    torch.manual_seed(0)
+    mf = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+    optf = torch.optim.AdamW(mf.parameters(), lr=1e-3, weight_decay=0.01)
+    mf, optf = accf.prepare(mf, optf)
+    raw = accf.unwrap_model(mf)
+    ref_train_unet.freeze_encoder(raw)
+    optf = accf.prepare(ref_train_unet.update_optimizer_for_frozen_encoder(raw, optf, 1e-3))
+    fl = [synth(2, 32, 900 + i, blocky=True) for i in range(3)]
+    res = ref_train_unet.train_one_epoch(mf, fl[:2], optf, accf, 0, args, loss_fn)
+    d["freeze/result_frozen"] = np.array([float(v) for v in res])
+    _, dig = param_digest(raw.state_dict())
+    d["freeze/param_digest_frozen"] = dig
+    d["freeze/frozen_grad_is_none"] = np.array([p.grad is None for p in raw.encoder.parameters()])
+    ref_train_unet.unfreeze_encoder(raw)
+    optf = accf.prepare(torch.optim.AdamW(raw.parameters(), lr=1e-3, weight_decay=0.01))
+    res = ref_train_unet.train_one_epoch(mf, fl[2:], optf, accf, 0, args, loss_fn)
+    d["freeze/result_unfrozen"] = np.array([float(v) for v in res])
+    _, dig = param_digest(raw.state_dict())
+    d["freeze/param_digest_unfrozen"] = dig
     np.savez_compressed(os.path.join(out, "loops.npz"), **d)
 
 
