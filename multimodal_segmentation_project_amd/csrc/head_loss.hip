@@ -19,7 +19,7 @@ namespace {
 constexpr int BLK = 256;
 constexpr int MAXC = MI3D_MAX_CLASSES;
 constexpr int CINB = 16;    // input-channel block of the 1x1x1 conv kernels
-constexpr int LOSS_MAXBLK = 1024;
+constexpr int LOSS_MAXBLK = 512;
 
 // ------------------------------------------------------------------------------------------ conv 1x1x1
 template <typename T, bool VEC>
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(1024) void seg_counts_finalize_kernel(const unsigne
     }
 }
 
-constexpr int METRIC_BLOCKS = 1024;
+constexpr int METRIC_BLOCKS = 512;
 inline int sgrid(int64_t total, int cap) {
     int64_t w = (total + BLK - 1) / BLK;
     return (int)(w < 1 ? 1 : (w > cap ? cap : w));
