@@ -80,10 +80,12 @@ __global__ __launch_bounds__(BLK) void pack_all_kernel(PackJobs J) {
         int CIBN = Cin / 16, COBN = Cout / 16;
         int cib = lb % CIBN, cob = lb / CIBN;
         const float* __restrict__ sc = J.j[ji].scale;          // inference: per-output-channel BatchNorm scale (forward image)
-        for (int idx = threadIdx.x; idx < 16 * 432; idx += BLK) {
-            int row = idx / 432, k = idx - row * 432;
-            float v = w[((int64_t)(cob * 16 + row) * Cin + cib * 16) * 27 + k];
-            wl[row * PK_LD + k] = sc ? v * sc[cob * 16 + row] : v;
+        for (int idx = threadIdx.x; idx < 16 * 108; idx += BLK) {        // 16-byte loads: a row's 432 floats start 16-B aligned
+            int row = idx / 108, k = (idx - row * 108) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(w + ((int64_t)(cob * 16 + row) * Cin + cib * 16) * 27 + k);
+            float f = sc ? sc[cob * 16 + row] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) wl[row * PK_LD + k + j] = v[j] * f;
         }
         __syncthreads();
         for (int q = threadIdx.x; q < 2 * 14 * 64; q += BLK) {
@@ -729,6 +731,7 @@ int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dg
 
 int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g, const float* scale) {
     MI3D_CHECK_ARG(J.n < MAX_PACK_JOBS && Cin % 16 == 0 && Cout % 16 == 0, "pack_all: too many jobs / bad channels");
+    MI3D_CHECK_ARG(((uintptr_t)w % 16) == 0, "pack_all: conv weight tensor must be 16-byte aligned");
     PackJob& j = J.j[J.n++];
     j = PackJob{w, wp_fwd, wp_dgrad, Cin, Cout, 0, persist_ok(Cin, Cout, g) ? 1 : 0, persist_ok(Cout, Cin, g) ? 1 : 0, J.nblocks, scale};
     J.nblocks += (Cin / 16) * (Cout / 16);
