@@ -186,6 +186,44 @@ int mi3d_preprocess_mri(const float* in, float* out, int64_t n, float p_low, flo
  * 2: CHAOS ranges {[55,70]:2, [110,135]:3, [175,200]:3, [240,255]:1, else 0} */
 int mi3d_remap_labels(const int64_t* in, int64_t* out, int64_t n, int kind, void* stream);
 
+/* Training-set augmentation, combined_transform() (utils/dataloader.py:223-262, used at train_unet.py:361): the
+ * arithmetic of MONAI's RandBiasField -> RandGaussianNoise -> RandAdjustContrast -> RandHistogramShift ->
+ * RandCoarseDropout on one (C, D, H, W) float volume, with the random parameters already drawn by the host
+ * (augment.py draws them from numpy RandomState streams laid out like MONAI's Compose).  A transform whose do_* flag
+ * (n_holes for the last) is 0 is skipped, as when MONAI's prob draw fails.
+ *   bias      x * exp(field), field = Legendre series (degree <= 3; coefficient order i, j, k with i + j + k <= degree
+ *             over the three spatial axes) on linspace(-1, 1, dim) float32 coordinates, evaluated in float64
+ *   noise     x + noise[i] (noise != NULL: host-drawn tensor, same shape) or x + N(noise_mean, noise_std) from the
+ *             library's counter-based generator seeded with noise_seed (same distribution, different stream)
+ *   contrast  ((x - min) / (max - min + 1e-7)) ** gamma * (max - min) + min, min / max over the whole volume
+ *   hist      piecewise-linear map through n_cp control points ref_cp -> flt_cp (both on [0, 1], scaled to [min, max])
+ *   holes     n_holes boxes [hole_lo, hole_lo + hole_size) over all channels set to fill_value */
+#define MI3D_AUG_MAX_COEFF 20
+#define MI3D_AUG_MAX_CP 16
+#define MI3D_AUG_MAX_HOLES 8
+typedef struct mi3d_aug_params {
+    int32_t do_bias, bias_degree;
+    double bias_coeff[MI3D_AUG_MAX_COEFF];
+    int32_t do_noise;
+    float noise_mean, noise_std;
+    uint64_t noise_seed;
+    int32_t do_contrast;
+    float gamma;
+    int32_t do_hist, n_cp;
+    float ref_cp[MI3D_AUG_MAX_CP], flt_cp[MI3D_AUG_MAX_CP];
+    int32_t n_holes;
+    int32_t hole_size[3];
+    int32_t hole_lo[MI3D_AUG_MAX_HOLES][3];
+    float fill_value;
+} mi3d_aug_params;
+size_t mi3d_augment_workspace_bytes(void);
+/* in == out allowed.  workspace: mi3d_augment_workspace_bytes(), 16-byte aligned. */
+int mi3d_augment(const float* in, float* out, const float* noise, int C, int D, int H, int W, const mi3d_aug_params* params,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* the label half of RandCoarseDropoutd: the same boxes set to `fill` in an int64 (C, D, H, W) label volume, in place */
+int mi3d_fill_boxes_i64(int64_t* label, int C, int D, int H, int W, int n_holes, const int32_t* hole_lo,
+                        const int32_t* hole_size, int64_t fill, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Per-operator entry points (channels-last activations; used by the parity tests and by stand-alone modules).
  * x/y: `dtype` tensors [N][D][H][W][C] with channel stride xcs/ycs (elements).

@@ -27,7 +27,18 @@ class LossCfg(C.Structure):
                 ("beta", C.c_float), ("eps", C.c_float), ("w_kd", C.c_float), ("temperature", C.c_float)]
 
 
-_DP, _LP = C.POINTER(UNetDesc), C.POINTER(LossCfg)
+AUG_MAX_COEFF, AUG_MAX_CP, AUG_MAX_HOLES = 20, 16, 8
+
+
+class AugParams(C.Structure):                      # mi3d_aug_params
+    _fields_ = [("do_bias", C.c_int32), ("bias_degree", C.c_int32), ("bias_coeff", C.c_double * AUG_MAX_COEFF),
+                ("do_noise", C.c_int32), ("noise_mean", C.c_float), ("noise_std", C.c_float), ("noise_seed", C.c_uint64),
+                ("do_contrast", C.c_int32), ("gamma", C.c_float), ("do_hist", C.c_int32), ("n_cp", C.c_int32),
+                ("ref_cp", C.c_float * AUG_MAX_CP), ("flt_cp", C.c_float * AUG_MAX_CP), ("n_holes", C.c_int32),
+                ("hole_size", C.c_int32 * 3), ("hole_lo", (C.c_int32 * 3) * AUG_MAX_HOLES), ("fill_value", C.c_float)]
+
+
+_DP, _LP, _AP = C.POINTER(UNetDesc), C.POINTER(LossCfg), C.POINTER(AugParams)
 
 # name -> (restype, argtypes); one line per symbol declared in include/mi3d.h
 _SIGS = {
@@ -62,6 +73,9 @@ _SIGS = {
     "mi3d_preprocess_mri_workspace_bytes": (sz, []),
     "mi3d_preprocess_mri": (i32, [vp, vp, i64, f32, f32, vp, vp]),
     "mi3d_remap_labels": (i32, [vp, vp, i64, i32, vp]),
+    "mi3d_augment_workspace_bytes": (sz, []),
+    "mi3d_augment": (i32, [vp, vp, vp, i32, i32, i32, i32, _AP, vp, sz, vp]),
+    "mi3d_fill_boxes_i64": (i32, [vp, i32, i32, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i64, vp]),
     "mi3d_conv3_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "mi3d_conv3_forward": (i32, [i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     "mi3d_conv3_backward": (i32, [i32, i32, vp, i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32,

@@ -426,7 +426,7 @@ int block_infer(const Ctx& c, int b, const float* x) {
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 2; }
+int mi3d_abi_version(void) { return 3; }
 
 int mi3d_unet_num_params(const mi3d_unet_desc* d) { return d ? 8 * (2 * d->n_levels + 1) + 2 * d->n_levels + 2 : -1; }
 int mi3d_unet_num_buffers(const mi3d_unet_desc* d) { return d ? 6 * (2 * d->n_levels + 1) : -1; }

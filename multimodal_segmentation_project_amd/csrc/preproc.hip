@@ -78,7 +78,19 @@ __global__ __launch_bounds__(BLK) void mri_sum_finalize_kernel(int nblk, int64_t
     for (int i = threadIdx.x; i < NSEL * 256; i += BLK) ws->hist[i / 256][i % 256] = 0u;
 }
 
-// histogram of key byte `pass` (most significant first) over the elements whose higher bytes equal the selection's prefix
+// histogram of key byte `pass` (most significant first) over the elements whose higher bytes equal the selection's prefix.
+// Selections that still share their prefix (all four in pass 0; each percentile's floor / ceil pair almost always) share
+// ONE histogram — that of the first selection with that prefix (its "leader") — so an element costs one LDS atomic per
+// distinct prefix, not four on the same address.
+__device__ __forceinline__ void sel_leaders(const unsigned* pf, int* lead) {
+#pragma unroll
+    for (int j = 0; j < NSEL; j++) {
+        lead[j] = j;
+#pragma unroll
+        for (int i = NSEL - 1; i >= 0; i--)
+            if (i < j && pf[i] == pf[j]) lead[j] = i;
+    }
+}
 __global__ __launch_bounds__(BLK) void mri_hist_kernel(const float* __restrict__ in, int64_t n, int pass, MriWs* ws) {
     __shared__ unsigned h[NSEL][256];
     for (int i = threadIdx.x; i < NSEL * 256; i += BLK) h[i / 256][i % 256] = 0u;
@@ -87,45 +99,69 @@ __global__ __launch_bounds__(BLK) void mri_hist_kernel(const float* __restrict__
     int shift = 24 - 8 * pass;
     unsigned mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
     unsigned pf[NSEL];
+    int lead[NSEL];
 #pragma unroll
     for (int j = 0; j < NSEL; j++) pf[j] = ws->prefix[j];
+    sel_leaders(pf, lead);
     for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
         unsigned k = okey((in[i] - mean) / sd);
         unsigned byte = (k >> shift) & 255u;
 #pragma unroll
         for (int j = 0; j < NSEL; j++)
-            if ((k & mask) == pf[j]) atomicAdd(&h[j][byte], 1u);
+            if (lead[j] == j && (k & mask) == pf[j]) atomicAdd(&h[j][byte], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NSEL * 256; i += BLK)
         if (h[i / 256][i % 256]) atomicAdd(&ws->hist[i / 256][i % 256], h[i / 256][i % 256]);
 }
-// pick the bucket holding the rank, descend; after the last pass the prefix IS the key of the order statistic
-__global__ void mri_pick_kernel(int pass, double q_lo, double q_hi, int64_t n, MriWs* ws) {
-    int j = threadIdx.x;
-    if (j < NSEL) {
-        unsigned long long r = ws->rank[j], acc = 0;
-        int b = 0;
-        for (; b < 256; b++) {
-            unsigned c = ws->hist[j][b];
-            if (acc + c > r) break;
-            acc += c;
-        }
-        if (b > 255) b = 255;
-        ws->rank[j] = r - acc;
-        ws->prefix[j] |= (unsigned)b << (24 - 8 * pass);
-        if (pass == 3) ws->sel[j] = ikey(ws->prefix[j]);
+// pick the bucket holding the rank, descend; after the last pass the prefix IS the key of the order statistic.
+// One wave per selection: lane l owns buckets 4l..4l+3, a wave prefix sum finds the bucket.  blockDim = 256.
+__global__ __launch_bounds__(BLK) void mri_pick_kernel(int pass, double q_lo, double q_hi, int64_t n, MriWs* ws) {
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned pf[NSEL];
+    int lead[NSEL];
+#pragma unroll
+    for (int q = 0; q < NSEL; q++) pf[q] = ws->prefix[q];
+    sel_leaders(pf, lead);
+    const unsigned long long r = ws->rank[j];
+    const uint4 c = *(const uint4*)&ws->hist[lead[j]][4 * lane];
+    const unsigned long long own = (unsigned long long)c.x + c.y + c.z + c.w;
+    unsigned long long incl = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned long long up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
     }
-    __syncthreads();
+    const unsigned long long excl = incl - own;
+    const unsigned long long total = __shfl(incl, 63);
+    const bool mine = total > r ? (excl <= r && r < incl) : lane == 63;     // (total <= r cannot happen; stay in range)
+    __syncthreads();                                                        // every read of hist / prefix / rank is done
+    if (mine) {
+        unsigned long long acc = excl;
+        int b = 4 * lane;
+        const unsigned cc[4] = {c.x, c.y, c.z, c.w};
+        int t = 0;
+        for (; t < 3; t++) {
+            if (acc + cc[t] > r) break;
+            acc += cc[t];
+        }
+        b += t;
+        ws->rank[j] = r - acc;
+        const unsigned np = pf[j] | ((unsigned)b << (24 - 8 * pass));
+        ws->prefix[j] = np;
+        if (pass == 3) ws->sel[j] = ikey(np);
+    }
     for (int i = threadIdx.x; i < NSEL * 256; i += blockDim.x) ws->hist[i / 256][i % 256] = 0u;
-    if (pass == 3 && threadIdx.x == 0) {
-        __threadfence_block();
-        double v0 = q_lo / 100.0 * (double)(n - 1), v1 = q_hi / 100.0 * (double)(n - 1);
-        double g0 = v0 - floor(v0), g1 = v1 - floor(v1);
-        double a0 = (double)ikey(ws->prefix[0]), b0 = (double)ikey(ws->prefix[1]);
-        double a1 = (double)ikey(ws->prefix[2]), b1 = (double)ikey(ws->prefix[3]);
-        ws->stat[2] = (float)(a0 + (b0 - a0) * g0);          // np.percentile lerp
-        ws->stat[3] = (float)(a1 + (b1 - a1) * g1);
+    if (pass == 3) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double v0 = q_lo / 100.0 * (double)(n - 1), v1 = q_hi / 100.0 * (double)(n - 1);
+            double g0 = v0 - floor(v0), g1 = v1 - floor(v1);
+            double a0 = (double)ikey(ws->prefix[0]), b0 = (double)ikey(ws->prefix[1]);
+            double a1 = (double)ikey(ws->prefix[2]), b1 = (double)ikey(ws->prefix[3]);
+            ws->stat[2] = (float)(a0 + (b0 - a0) * g0);          // np.percentile lerp
+            ws->stat[3] = (float)(a1 + (b1 - a1) * g1);
+        }
     }
 }
 __global__ __launch_bounds__(BLK) void mri_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, const MriWs* ws) {

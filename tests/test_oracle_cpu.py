@@ -298,3 +298,66 @@ def test_oracle_preprocessing_matches_reference(golden):
         img = preproc_ref.preprocess(g[f"{name}/image_in"], name)
         np.testing.assert_allclose(np.asarray(img, np.float32), g[f"{name}/image_out"], rtol=0, atol=1e-7, err_msg=name)
         np.testing.assert_array_equal(preproc_ref.remap_labels(g[f"{name}/label_in"], name), g[f"{name}/label_out"], err_msg=name)
+
+
+def test_augment_restatement_is_self_consistent():
+    """SURVEY §8 F4 augmentation chain (utils/dataloader.py:223-262).  MONAI is absent (parity unpinned): what CAN be
+    checked on the CPU is the restatement against independent formulations of the same published algorithms."""
+    from oracle import augment_ref as A
+    rng = np.random.RandomState(5)
+    # bias field: leggrid3d with MONAI's coefficient placement == explicit sum over (i, j, k), i + j + k <= 3
+    shape = (6, 5, 7)
+    coeff = rng.uniform(0, 0.1, A.n_bias_coeff()).tolist()
+    assert A.n_bias_coeff() == 20
+    field = A.bias_field(shape, coeff)
+    P = [lambda x: np.ones_like(x), lambda x: x, lambda x: 0.5 * (3 * x * x - 1), lambda x: 0.5 * (5 * x ** 3 - 3 * x)]
+    cs = [np.linspace(-1, 1, n, dtype=np.float32).astype(np.float64) for n in shape]
+    want, c = np.zeros(shape), 0
+    for i in range(4):
+        for j in range(4 - i):
+            for k in range(4 - i - j):
+                want += coeff[c] * P[i](cs[0])[:, None, None] * P[j](cs[1])[None, :, None] * P[k](cs[2])[None, None, :]
+                c += 1
+    assert c == 20 and np.abs(field - want).max() < 1e-14
+    # histogram shift == np.interp on the scaled control points
+    img = rng.rand(1, 6, 5, 7).astype(np.float32) * 3 - 1
+    ref = np.linspace(0, 1, 5)
+    flt = np.array([0, 0.1, 0.45, 0.9, 1.0])
+    got = A.histogram_shift(img, ref, flt)
+    lo, hi = img.min(), img.max()
+    assert np.abs(got - np.interp(img, ref * (hi - lo) + lo, flt * (hi - lo) + lo)).max() < 1e-5
+    assert np.array_equal(A.histogram_shift(np.full((1, 2, 2, 2), 3.0, np.float32), ref, flt), np.full((1, 2, 2, 2), 3.0, np.float32))
+    # contrast keeps the range and is the identity at gamma 1
+    out = A.adjust_contrast(img, 1.0)
+    assert np.abs(out - img).max() < 1e-5
+    out = A.adjust_contrast(img, 0.7)
+    assert abs(out.min() - lo) < 1e-6 and abs(out.max() - hi) < 1e-5 and (out >= img - 1e-6).all()
+    # coarse dropout: both keys get the same boxes, every channel
+    lab = rng.randint(1, 4, (1, 6, 5, 7))
+    a = A.coarse_dropout(img, [(1, 0, 2), (3, 2, 4)], (2, 2, 3), 0.0)
+    b = A.coarse_dropout(lab, [(1, 0, 2), (3, 2, 4)], (2, 2, 3), 0)
+    assert ((a == 0) == (b == 0)).all() and (b == 0).sum() == 2 * 12
+
+
+def test_augment_host_draws_match_restatement():
+    """The product's host-side draws (augment.CombinedTransform.draw) and the oracle's follow the same stream layout."""
+    from oracle import augment_ref as A
+    from multimodal_segmentation_project_amd import augment
+    tf = augment.combined_transform(prob=0.6, noise="host").set_random_state(1234)
+    st = A.Streams(1234)
+    fired = np.zeros(5, int)
+    for _ in range(12):
+        p = tf.draw((1, 20, 24, 18))
+        q = A.draw_params(st, (1, 20, 24, 18), prob=0.6)
+        for name, idx in (("bias_coeff", 0), ("noise", 1), ("gamma", 2), ("ref_cp", 3), ("hole_lo", 4)):
+            a, b = getattr(p, name), q[name]
+            assert (a is None) == (b is None), name
+            if a is not None:
+                fired[idx] += 1
+                assert np.array_equal(np.asarray(a), np.asarray(b)), name
+        if p.ref_cp is not None:
+            assert np.array_equal(p.flt_cp, q["flt_cp"]) and (np.diff(p.flt_cp) >= 0).all()
+        if p.hole_lo is not None:
+            assert p.hole_size == q["hole_size"] == (16, 16, 16)
+            assert all(0 <= lo[i] <= (20, 24, 18)[i] - 16 for lo in p.hole_lo for i in range(3))
+    assert (fired > 0).all()
