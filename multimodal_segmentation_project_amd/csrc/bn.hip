@@ -288,6 +288,68 @@ __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
+// Second half of an encoder block: the same apply pass, one thread per 2x2x2 pooling window and channel group — writes the
+// eight activated voxels (the skip tensor) AND their maximum (MaxPool3d(2,2), models/unet.py:40,71), so the pooling launch and
+// its re-read of the skip tensor disappear.  Even D, H, W only (every voxel lies in exactly one window).
+template <typename T, int VEC, bool TRAIN>
+__global__ __launch_bounds__(BLK) void bn_apply_pool_kernel(const T* __restrict__ y, int ycs, int C, int N, int D, int H, int W,
+                                                            float* __restrict__ stat, BnPart tr, const float* __restrict__ drop,
+                                                            T* __restrict__ z, int zcs, T* __restrict__ pl, int pcs) {
+    const int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+    const unsigned gtid = blockIdx.x * BLK + threadIdx.x;
+    const int g = (int)(gtid % (unsigned)G);
+    float a[VEC], b[VEC];
+    if constexpr (TRAIN) {
+        __shared__ double red[BLK * 4];
+        __shared__ float ab[2 * MAXC_BN];
+        bn_train_coeffs(tr, C, stat, ab, red);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { a[i] = ab[g * VEC + i]; b[i] = ab[MAXC_BN + g * VEC + i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i]; }
+    }
+    const unsigned windows = (unsigned)N * Do * Ho * Wo, wstep = (gridDim.x * BLK) / (unsigned)G;
+    float ds[VEC];
+    int dn = -1;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) ds[i] = 1.f;
+    for (unsigned win = gtid / (unsigned)G; win < windows; win += wstep) {
+        unsigned r = win;
+        const int wo = (int)(r % (unsigned)Wo); r /= (unsigned)Wo;
+        const int ho = (int)(r % (unsigned)Ho); r /= (unsigned)Ho;
+        const int d_o = (int)(r % (unsigned)Do);
+        const int n = (int)(r / (unsigned)Do);
+        if (drop && n != dn) {
+            dn = n;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) ds[i] = drop[(int64_t)n * C + g * VEC + i];
+        }
+        float v[8][VEC], m[VEC];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t off = (((int64_t)n * D + 2 * d_o + (k >> 2)) * H + 2 * ho + ((k >> 1) & 1)) * W + 2 * wo + (k & 1);
+            ldv<T, VEC>(y + off * ycs + g * VEC, v[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; i++) m[i] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t off = (((int64_t)n * D + 2 * d_o + (k >> 2)) * H + 2 * ho + ((k >> 1) & 1)) * W + 2 * wo + (k & 1);
+            float o[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                float t = fmaf(v[k][i], a[i], b[i]);
+                t = t > 0.f ? t : 0.f;
+                o[i] = (float)(T)(t * ds[i]);             // the pooled value is the maximum of the STORED (rounded) values
+                m[i] = o[i] > m[i] ? o[i] : m[i];
+            }
+            stv<T, VEC>(z + off * zcs + g * VEC, o);
+        }
+        stv<T, VEC>(pl + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * pcs + g * VEC, m);
+    }
+}
+
 // nred = blocks of the reduction proper (= gridDim.x unless a slab-sum job rides behind them, see bn_bwd).
 // skp != NULL: dz arrives as the ks fp32 split-K partials of the input-gradient conv that produced it ([ks][M][C]); they
 // are summed and rounded HERE and dz is written for the apply pass -- the split-K finishing launch disappears
@@ -558,6 +620,31 @@ int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int6
         else if (v8) bn_apply_kernel<T, 8, false><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
         else if (small) bn_apply_kernel<T, 1, true><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
         else bn_apply_kernel<T, 1, false><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
+        MI3D_LAUNCH_CHECK();
+    });
+    return 0;
+}
+
+int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, float* stat, const float* drop, void* z, int zcs,
+                            void* pooled, int pcs, hipStream_t s, const BnSmall* small) {
+    const int64_t M = g.M();
+    MI3D_CHECK_ARG(C >= 1 && M >= 1 && g.D % 2 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && M * C < (1ll << 31),
+                   "bn_apply_pool: needs even sides and fewer than 2^31 elements");
+    BnPart t{};
+    if (small) {
+        MI3D_CHECK_ARG(small->part && small->nrows >= 1 && small->nrows <= SMALL_ROWS && C <= MAXC_BN && small->gamma && small->beta,
+                       "bn_apply_pool: bad partial statistics");
+        t = BnPart{small->part, small->nrows, M, small->gamma, small->beta, small->running_mean, small->running_var,
+                   small->num_batches_tracked, small->momentum, small->eps};
+    }
+    DISPATCH_T(dtype, T, {
+        bool v8 = vec8_ok(C, ycs, zcs, y, z, sizeof(T)) && pcs % 8 == 0 && ((uintptr_t)pooled % 16 == 0);
+        int grid = v8 ? stream_grid(M / 8 * (C / 8), C / 8) : stream_grid(M / 8 * C, C);
+        const T* yp = (const T*)y; T* zp = (T*)z; T* pp = (T*)pooled;
+        if (v8 && small) bn_apply_pool_kernel<T, 8, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
+        else if (v8) bn_apply_pool_kernel<T, 8, false><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
+        else if (small) bn_apply_pool_kernel<T, 1, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
+        else bn_apply_pool_kernel<T, 1, false><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
         MI3D_LAUNCH_CHECK();
     });
     return 0;

@@ -116,6 +116,9 @@ int bn_fold_all(const BnFoldJobs& J, hipStream_t s);
 // running statistics / num_batches_tracked are updated here
 int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int64_t V, float* stat,
                        const float* drop, void* z, int zcs, hipStream_t s, const BnSmall* small = nullptr);
+// the same pass fused with MaxPool3d(2,2): writes z AND pooled = max over each 2x2x2 window of z (even D, H, W only)
+int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, float* stat, const float* drop, void* z, int zcs,
+                            void* pooled, int pcs, hipStream_t s, const BnSmall* small = nullptr);
 // dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)), dyh = dz*drop*[a*y+b > 0]; dgamma, dbeta (+)=
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,

@@ -234,7 +234,9 @@ void block_output(const Ctx& c, int b, void*& ptr, int& cs) {
     else { ptr = c.at(p.zd[b - p.L - 1]); cs = p.C[p.blk[b].level]; }
 }
 
-int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, const float* drop, int training) {
+// pooled != NULL (encoder blocks on even volumes): the second apply pass also writes MaxPool3d(2,2) of the block output
+int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, const float* drop, int training,
+                  void* pooled = nullptr, int pcs = 0) {
     const Plan& p = c.p;
     const BlockP& B = p.blk[b];
     Geo g = p.geo[B.level];
@@ -296,8 +298,13 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
         BnSmall sm{nosplit ? c.at<float>(p.statpart) : c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps};
-        MI3D_TRY(bn_apply_relu_drop(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
-                                    (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, c.s, small_rows > 0 ? &sm : nullptr));
+        if (h == 1 && pooled)
+            MI3D_TRY(bn_apply_relu_drop_pool(p.dt, c.at(H.y), H.Cout, H.Cout, g, c.at<float>(H.stat),
+                                             (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, pooled, pcs, c.s,
+                                             small_rows > 0 ? &sm : nullptr));
+        else
+            MI3D_TRY(bn_apply_relu_drop(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
+                                        (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, c.s, small_rows > 0 ? &sm : nullptr));
     }
     return 0;
 }
@@ -489,8 +496,9 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
         c.packed = true;
     }
     for (int l = 0; l < L; l++) {
-        MI3D_TRY(block_forward(c, l, x, buffers, drop_scales, training));
-        MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), p.catcs(l), p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
+        const bool even = p.geo[l].D % 2 == 0 && p.geo[l].H % 2 == 0 && p.geo[l].W % 2 == 0 && !getenv("MI3D_NO_POOL_FUSE");
+        MI3D_TRY(block_forward(c, l, x, buffers, drop_scales, training, even ? c.at(p.pool[l]) : nullptr, p.C[l]));
+        if (!even) MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), p.catcs(l), p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
     }
     MI3D_TRY(block_forward(c, L, x, buffers, drop_scales, training));
     if (gap_out) MI3D_TRY(gap_fwd(p.dt, c.at(p.zb), p.C[L], p.C[L], d->N, p.geo[L].V(), gap_out, c.s));
