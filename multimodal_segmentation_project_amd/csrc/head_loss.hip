@@ -300,7 +300,7 @@ __device__ __forceinline__ void softmax_c(const float (&z)[NC], int C, float inv
     float se = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; c++) { p[c] = c < C ? __expf(z[c] * inv_t - mx) : 0.f; se += p[c]; }
-    float r = 1.f / se;
+    float r = __builtin_amdgcn_rcpf(se);          // 1 ulp; the IEEE division costs ~10 VALU slots per voxel in VALU-bound passes
 #pragma unroll
     for (int c = 0; c < NC; c++) p[c] *= r;
     lse = mx + __logf(se);
@@ -334,25 +334,30 @@ __device__ __forceinline__ void load_labels(const int64_t* __restrict__ lb, int 
 constexpr int NQ = 2 + 3 * MAXC;   // ce, kl, I[c], P[c], T[c]
 
 // METRICS: the same pass also produces the argmax / label count partials of seg_metrics_kernel (the training step needs
-// both on the same logits: one read of logits + labels instead of two)
-template <int NC, int VV, bool METRICS>
+// both on the same logits: one read of logits + labels instead of two).
+// The pass is VALU-bound (4 classes: softmax + per-class sums + argmax per voxel), so what can leave the vector unit does:
+// EXACT (C == NC) drops every `c < C` predicate, TEACH compiles the distillation term in or out, and the integer counts
+// (label histogram, argmax histogram, intersections) are wave ballots + scalar popcounts — the vector unit only does the
+// compares.  T[c] = sum [t == c] is taken from the exact label histogram instead of a float accumulator.
+template <int NC, int VV, bool METRICS, bool EXACT, bool TEACH>
 __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ teacher, int C, int64_t V,
+                                                           const float* __restrict__ teacher, int C_, int64_t V,
                                                            float inv_t, double* __restrict__ part,
                                                            unsigned long long* __restrict__ counts) {
+    const int C = EXACT ? NC : C_;
     constexpr int NQL = 2 + 3 * NC;
     __shared__ float red[4][NQL];
     __shared__ unsigned redc[4][3 * NC + 1];
-    unsigned ni[NC], np[NC], nt[NC], nc = 0;
+    unsigned ni[NC], np[NC], nt[NC];                 // wave-uniform (scalar registers)
 #pragma unroll
     for (int c = 0; c < NC; c++) ni[c] = np[c] = nt[c] = 0;
     int n = blockIdx.y;
     const float* lg = logits + (int64_t)n * C * V;
-    const float* tg = teacher ? teacher + (int64_t)n * C * V : nullptr;
+    const float* tg = TEACH ? teacher + (int64_t)n * C * V : nullptr;
     const int64_t* lb = labels + (int64_t)n * V;
-    float q[NQL];
+    float q[2 + 2 * NC];                             // ce, kl, I[c], P[c]
 #pragma unroll
-    for (int i = 0; i < NQL; i++) q[i] = 0.f;
+    for (int i = 0; i < 2 + 2 * NC; i++) q[i] = 0.f;
     int64_t ngrp = V / VV;
     for (int64_t grp = (int64_t)blockIdx.x * BLK + threadIdx.x; grp < ngrp; grp += (int64_t)gridDim.x * BLK) {
         int64_t v0 = grp * VV;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restri
         load_planes<NC, VV>(lg, C, V, v0, z);
         load_labels<VV>(lb + v0, t);
         float zt_[VV][NC];
-        if (tg) load_planes<NC, VV>(tg, C, V, v0, zt_);
+        if constexpr (TEACH) load_planes<NC, VV>(tg, C, V, v0, zt_);
 #pragma unroll
         for (int k = 0; k < VV; k++) {
             float p[NC], lse;
@@ -369,73 +374,78 @@ __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restri
             float zt = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                if (c < C) {
+                if (EXACT || c < C) {
                     bool is = (c == t[k]);
                     zt = is ? z[k][c] : zt;
                     q[2 + c] += is ? p[c] : 0.f;
                     q[2 + NC + c] += p[c];
-                    q[2 + 2 * NC + c] += is ? 1.f : 0.f;
                 }
             }
             q[0] += lse - zt;
-            if constexpr (METRICS) {
+            {
                 float bvv = z[k][0];
                 int best = 0;
 #pragma unroll
                 for (int c = 1; c < NC; c++)
-                    if (c < C && z[k][c] > bvv) { bvv = z[k][c]; best = c; }
+                    if ((EXACT || c < C) && z[k][c] > bvv) { bvv = z[k][c]; best = c; }
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    ni[c] += (best == c && t[k] == c) ? 1u : 0u;
-                    np[c] += (best == c) ? 1u : 0u;
-                    nt[c] += (t[k] == c) ? 1u : 0u;
+                    unsigned long long mt = __ballot(t[k] == c);
+                    nt[c] += (unsigned)__popcll(mt);
+                    if constexpr (METRICS) {
+                        unsigned long long mb = __ballot(best == c);
+                        np[c] += (unsigned)__popcll(mb);
+                        ni[c] += (unsigned)__popcll(mb & mt);
+                    }
                 }
-                nc += (best == t[k]) ? 1u : 0u;
             }
-            if (tg) {
+            if constexpr (TEACH) {
                 float ps[NC], pt[NC], ls, lt;
                 softmax_c<NC>(z[k], C, inv_t, ps, ls);
                 softmax_c<NC>(zt_[k], C, inv_t, pt, lt);
                 float kl = 0.f;
 #pragma unroll
                 for (int c = 0; c < NC; c++)
-                    if (c < C && pt[c] > 0.f) kl += pt[c] * ((zt_[k][c] * inv_t - lt) - (z[k][c] * inv_t - ls));
+                    if ((EXACT || c < C) && pt[c] > 0.f) kl += pt[c] * ((zt_[k][c] * inv_t - lt) - (z[k][c] * inv_t - ls));
                 q[1] += kl;
             }
         }
     }
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < NQL; i++) {
+    for (int i = 0; i < 2 + 2 * NC; i++) {
         float sv = wave_sum(q[i]);
         if (lane == 0) red[wave][i] = sv;
     }
-    __syncthreads();
-    if (threadIdx.x < NQ) {                                    // partial row in the MAXC layout the finalize reads
-        int i = threadIdx.x, src = -1;
-        if (i < 2) src = i;
-        else { int k = (i - 2) / MAXC, c = (i - 2) % MAXC; if (c < NC) src = 2 + k * NC + c; }
-        double v = 0.0;
-        if (src >= 0) v = (double)red[0][src] + (double)red[1][src] + (double)red[2][src] + (double)red[3][src];
-        part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NQ + i] = v;
-    }
-    if constexpr (METRICS) {
-        auto wsum = [&](unsigned v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+    if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            unsigned a = wsum(ni[c]), b = wsum(np[c]), d = wsum(nt[c]);
-            if (lane == 0) { redc[wave][c] = a; redc[wave][NC + c] = b; redc[wave][2 * NC + c] = d; }
+            red[wave][2 + 2 * NC + c] = (float)nt[c];                     // exact: a wave sees < 2^24 voxels per block
+            redc[wave][c] = ni[c]; redc[wave][NC + c] = np[c]; redc[wave][2 * NC + c] = nt[c];
         }
-        unsigned e = wsum(nc);
-        if (lane == 0) redc[wave][3 * NC] = e;
-        __syncthreads();
-        if (threadIdx.x < 3 * MAXC + 1) {
-            int i = threadIdx.x, src = -1;
-            if (i == 3 * MAXC) src = 3 * NC;
-            else { int k = i / MAXC, c = i % MAXC; if (c < NC) src = k * NC + c; }
+    }
+    __syncthreads();
+    // partial rows are COMPACT: 2 + 3C doubles (ce, kl, I[c], P[c], T[c]) and 3C + 1 counts — the single finalize
+    // workgroup is bound by pulling the rows through one CU
+    const int nqc = 2 + 3 * C;
+    if ((int)threadIdx.x < nqc) {
+        int i = threadIdx.x, src = i;
+        if (i >= 2) { int k = (i - 2) / C, c = (i - 2) % C; src = 2 + k * NC + c; }
+        double v = (double)red[0][src] + (double)red[1][src] + (double)red[2][src] + (double)red[3][src];
+        part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * nqc + i] = v;
+    }
+    if constexpr (METRICS) {
+        if ((int)threadIdx.x < 3 * C + 1) {
+            int i = threadIdx.x;
             unsigned long long v = 0;
-            if (src >= 0) v = (unsigned long long)redc[0][src] + redc[1][src] + redc[2][src] + redc[3][src];
-            counts[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (3 * MAXC + 1) + i] = v;
+            if (i < 3 * C) {
+                int src = (i / C) * NC + (i % C);
+                v = (unsigned long long)redc[0][src] + redc[1][src] + redc[2][src] + redc[3][src];
+            } else {                                            // n_correct = sum_c n_inter[c]
+#pragma unroll
+                for (int c = 0; c < NC; c++) v += (unsigned long long)redc[0][c] + redc[1][c] + redc[2][c] + redc[3][c];
+            }
+            counts[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (3 * C + 1) + i] = v;
         }
     }
 }
@@ -446,11 +456,14 @@ __device__ __forceinline__ void seg_loss_finalize_body(const double* __restrict_
                                                        int64_t V, LossCfg cfg, float* loss_out, float* coef) {
     __shared__ double sums[NQ];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int q = wave; q < NQ; q += 16) {
+    const int nqc = 2 + 3 * C;
+    if (threadIdx.x < NQ) sums[threadIdx.x] = 0.0;
+    __syncthreads();
+    for (int q = wave; q < nqc; q += 16) {
         double s = 0.0;
-        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * NQ + q];
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * nqc + q];
         s = wave_sum_d(s);
-        if (lane == 0) sums[q] = s;
+        if (lane == 0) sums[q < 2 ? q : 2 + ((q - 2) / C) * MAXC + (q - 2) % C] = s;      // -> the MAXC layout used below
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -491,14 +504,15 @@ __global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* _
     seg_loss_finalize_body(part, nblk, N, C, V, cfg, loss_out, coef);
 }
 
-template <int NC, int VV>
+template <int NC, int VV, bool EXACT, bool TEACH>
 __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ teacher, int C, int64_t V,
+                                                           const float* __restrict__ teacher, int C_, int64_t V,
                                                            float inv_t, const float* __restrict__ coef,
                                                            const float* __restrict__ grad_out, float* __restrict__ dlogits) {
+    const int C = EXACT ? NC : C_;
     int n = blockIdx.y;
     const float* lg = logits + (int64_t)n * C * V;
-    const float* tg = teacher ? teacher + (int64_t)n * C * V : nullptr;
+    const float* tg = TEACH ? teacher + (int64_t)n * C * V : nullptr;
     const int64_t* lb = labels + (int64_t)n * V;
     float* dg = dlogits + (int64_t)n * C * V;
     float go = grad_out ? grad_out[0] : 1.f;
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restri
         load_planes<NC, VV>(lg, C, V, v0, z);
         load_labels<VV>(lb + v0, t);
         float zt_[VV][NC];
-        if (tg) load_planes<NC, VV>(tg, C, V, v0, zt_);
+        if constexpr (TEACH) load_planes<NC, VV>(tg, C, V, v0, zt_);
 #pragma unroll
         for (int k = 0; k < VV; k++) {
             float p[NC], g[NC], lse;
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restri
             float kd[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) kd[c] = 0.f;
-            if (tg) {
+            if constexpr (TEACH) {
                 float ps[NC], pt[NC], ls, lt;
                 softmax_c<NC>(z[k], C, inv_t, ps, ls);
                 softmax_c<NC>(zt_[k], C, inv_t, pt, lt);
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restri
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            if (c < C) {
+            if (EXACT || c < C) {
                 if constexpr (VV == 4) *reinterpret_cast<float4*>(dg + (int64_t)c * V + v0) = float4{o[0][c], o[1][c], o[2][c], o[3][c]};
                 else dg[(int64_t)c * V + v0] = o[0][c];
             }
@@ -594,13 +608,11 @@ __global__ __launch_bounds__(BLK) void seg_metrics_kernel(const float* __restric
     unsigned e = wsum(nc);
     if (lane == 0) red[wave][3 * NC] = e;
     __syncthreads();
-    if (threadIdx.x < 3 * MAXC + 1) {
-        int i = threadIdx.x, src = -1;
-        if (i == 3 * MAXC) src = 3 * NC;
-        else { int k = i / MAXC, c = i % MAXC; if (c < NC) src = k * NC + c; }
-        unsigned long long v = 0;
-        if (src >= 0) v = (unsigned long long)red[0][src] + red[1][src] + red[2][src] + red[3][src];
-        counts[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (3 * MAXC + 1) + i] = v;
+    if ((int)threadIdx.x < 3 * C + 1) {                       // compact row: 3C + 1 counts
+        int i = threadIdx.x;
+        int src = i == 3 * C ? 3 * NC : (i / C) * NC + (i % C);
+        unsigned long long v = (unsigned long long)red[0][src] + red[1][src] + red[2][src] + red[3][src];
+        counts[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (3 * C + 1) + i] = v;
     }
 }
 
@@ -609,11 +621,14 @@ __device__ __forceinline__ void seg_metrics_finalize_body(const unsigned long lo
                                                           int D, int64_t V, float* out) {
     __shared__ unsigned long long counts[3 * MAXC + 1];
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int q = wave; q < 3 * MAXC + 1; q += 16) {         // exact integer sums, wave-parallel
+    const int ncc = 3 * C + 1;
+    if (threadIdx.x < 3 * MAXC + 1) counts[threadIdx.x] = 0;
+    __syncthreads();
+    for (int q = wave; q < ncc; q += 16) {                  // exact integer sums, wave-parallel
         unsigned long long s = 0;
-        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * (3 * MAXC + 1) + q];
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * ncc + q];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) counts[q] = s;
+        if (lane == 0) counts[q == 3 * C ? 3 * MAXC : (q / C) * MAXC + q % C] = s;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -652,14 +667,11 @@ __global__ __launch_bounds__(1024) void seg_loss_metrics_finalize_kernel(const d
 // [2C..3C) n_tgt, [3C] n_correct  (int64)
 __global__ __launch_bounds__(1024) void seg_counts_finalize_kernel(const unsigned long long* part, int nblk, int C, long long* out) {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int q = wave; q < 3 * MAXC + 1; q += 16) {
+    for (int q = wave; q < 3 * C + 1; q += 16) {            // rows and output share the compact layout
         unsigned long long s = 0;
-        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * (3 * MAXC + 1) + q];
+        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * (3 * C + 1) + q];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) {
-            if (q == 3 * MAXC) out[3 * C] = (long long)s;
-            else { int k = q / MAXC, c = q % MAXC; if (c < C) out[k * C + c] = (long long)s; }
-        }
+        if (lane == 0) out[q] = (long long)s;
     }
 }
 
@@ -753,15 +765,23 @@ int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teache
     float it = 1.f / cfg.temp;
     bool met = metrics_out && metrics_ws;
     unsigned long long* cw = (unsigned long long*)metrics_ws;
+#define SLF3(NC_, VV_, EX_, TE_)                                                                                          \
+    do {                                                                                                                   \
+        if (met) seg_loss_fwd_kernel<NC_, VV_, true, EX_, TE_><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws, cw);   \
+        else seg_loss_fwd_kernel<NC_, VV_, false, EX_, TE_><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws, nullptr); \
+    } while (0)
 #define SLF(NC_, VV_)                                                                                                      \
     do {                                                                                                                   \
-        if (met) seg_loss_fwd_kernel<NC_, VV_, true><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws, cw);   \
-        else seg_loss_fwd_kernel<NC_, VV_, false><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, (double*)ws, nullptr); \
+        if (C == NC_ && tch) SLF3(NC_, VV_, true, true);                                                                  \
+        else if (C == NC_) SLF3(NC_, VV_, true, false);                                                                   \
+        else if (tch) SLF3(NC_, VV_, false, true);                                                                        \
+        else SLF3(NC_, VV_, false, false);                                                                                \
     } while (0)
     if (C <= 4 && v4) SLF(4, 4);
     else if (C <= 4) SLF(4, 1);
     else if (v4) SLF(MAXC, 4);
     else SLF(MAXC, 1);
+#undef SLF3
 #undef SLF
     MI3D_LAUNCH_CHECK();
     if (met) seg_loss_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, cw, bx * N, N, C, D, V, cfg, loss_out, coef, metrics_out);
@@ -777,10 +797,20 @@ int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teache
     bool v4 = vv4(V, logits, labels, tch) && al16(dlogits);
     dim3 grid((unsigned)per_sample_blocks(V, v4 ? 4 : 1, N, 4096), (unsigned)N);
     float it = 1.f / cfg.temp;
-    if (C <= 4 && v4) seg_loss_bwd_kernel<4, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
-    else if (C <= 4) seg_loss_bwd_kernel<4, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
-    else if (v4) seg_loss_bwd_kernel<MAXC, 4><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
-    else seg_loss_bwd_kernel<MAXC, 1><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits);
+#define SLB3(NC_, VV_, EX_, TE_) seg_loss_bwd_kernel<NC_, VV_, EX_, TE_><<<grid, BLK, 0, s>>>(logits, labels, tch, C, V, it, coef, grad_out, dlogits)
+#define SLB(NC_, VV_)                                                         \
+    do {                                                                      \
+        if (C == NC_ && tch) SLB3(NC_, VV_, true, true);                      \
+        else if (C == NC_) SLB3(NC_, VV_, true, false);                       \
+        else if (tch) SLB3(NC_, VV_, false, true);                            \
+        else SLB3(NC_, VV_, false, false);                                    \
+    } while (0)
+    if (C <= 4 && v4) SLB(4, 4);
+    else if (C <= 4) SLB(4, 1);
+    else if (v4) SLB(MAXC, 4);
+    else SLB(MAXC, 1);
+#undef SLB
+#undef SLB3
     MI3D_LAUNCH_CHECK();
     return 0;
 }
