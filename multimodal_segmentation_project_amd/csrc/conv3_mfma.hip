@@ -430,10 +430,7 @@ __device__ __forceinline__ void conv3_mfma_persist_body(Bid bid_, const bf16* __
         pk[it >> 1] |= (unsigned)(ix | (iy << 5) | (iz << 9)) << ((it & 1) * 16);
     }
     bf16x8 wf[WLDS ? 1 : NCH][WLDS ? 1 : 14][COB];
-    if constexpr (WLDS) {
-        for (int i = threadIdx.x; i < NWF * 64; i += BLK)
-            *reinterpret_cast<bf16x8*>(wl + i * 8) = *reinterpret_cast<const bf16x8*>(wp + (int64_t)i * 8);
-    } else {
+    if constexpr (!WLDS) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++)
 #pragma unroll
@@ -496,6 +493,12 @@ __device__ __forceinline__ void conv3_mfma_persist_body(Bid bid_, const bf16* __
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
     if (tile < ntiles) load_pieces(tile, 0);
+    // weights -> LDS AFTER the first tile's loads are in flight (both are cold fetches; the tile loop's first barrier orders
+    // these LDS writes before any fragment read)
+    if constexpr (WLDS) {
+        for (int i = threadIdx.x; i < NWF * 64; i += BLK)
+            *reinterpret_cast<bf16x8*>(wl + i * 8) = *reinterpret_cast<const bf16x8*>(wp + (int64_t)i * 8);
+    }
     for (; tile < ntiles; tile += bid_.gx) {
         f32x4 acc[MB][COB];
 #pragma unroll
