@@ -496,7 +496,9 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
         c.packed = true;
     }
     for (int l = 0; l < L; l++) {
-        const bool even = p.geo[l].D % 2 == 0 && p.geo[l].H % 2 == 0 && p.geo[l].W % 2 == 0 && !getenv("MI3D_NO_POOL_FUSE");
+        // fused apply + pool: even sides (every voxel in exactly one window) and 32-bit element indices
+        const bool even = p.geo[l].D % 2 == 0 && p.geo[l].H % 2 == 0 && p.geo[l].W % 2 == 0 &&
+                          p.geo[l].M() * p.C[l] < (1ll << 31) && !getenv("MI3D_NO_POOL_FUSE");
         MI3D_TRY(block_forward(c, l, x, buffers, drop_scales, training, even ? c.at(p.pool[l]) : nullptr, p.C[l]));
         if (!even) MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), p.catcs(l), p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
     }

@@ -473,6 +473,13 @@ def test_layout_and_kernel_choices_are_invisible(monkeypatch):
     assert l0 == l1 and torch.equal(o0, o1)
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
+    # BN-apply + max-pool in one launch vs two: the pooled value is the maximum of the same rounded activations -> bitwise
+    monkeypatch.setenv("MI3D_NO_POOL_FUSE", "1")
+    l4, o4, g4 = run()
+    assert l0 == l4 and torch.equal(o0, o4)
+    for a, b in zip(g0, g4):
+        assert torch.equal(a, b)
+    monkeypatch.delenv("MI3D_NO_POOL_FUSE")
     # fused backward launches (dgrad + wgrad, upconv data + weight gradient) off: same kernels bodies, only the
     # weight-gradient slab partition (summation order) changes
     monkeypatch.setenv("MI3D_NO_FUSED_BWD", "1")
