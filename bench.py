@@ -247,5 +247,22 @@ def main():
         dist.destroy_process_group()
 
 
+def _main_with_clean_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner on every
+    rank when its first communicator is created), so the process runs with file descriptor 1 pointing at stderr and only
+    the result lines reach the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    out = os.fdopen(real, "w")
+    py_stdout = sys.stdout
+    sys.stdout = out
+    try:
+        main()
+    finally:
+        out.flush()
+        sys.stdout = py_stdout
+
+
 if __name__ == "__main__":
-    main()
+    _main_with_clean_stdout()
