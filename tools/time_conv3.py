@@ -41,7 +41,7 @@ def run(cin, cout, S, N, reps=30, bwd=False):
     torch.cuda.synchronize()
     us = a.elapsed_time(e) / reps * 1e3
     gf = 2 * 27 * cin * cout * N * S ** 3 * (2 if bwd else 1) / 1e9
-    print(f"conv3 {'bwd' if bwd else 'fwd'} {cin:3d}->{cout:3d} {S}^3 N={N}: {us:8.1f} us/call  {gf / us / 1e3:6.2f} TFLOP/s (incl. pack)")
+    print(f"conv3 {'bwd' if bwd else 'fwd'} {cin:3d}->{cout:3d} {S}^3 N={N}: {us:8.1f} us/call  {gf / us * 1e3:7.1f} TFLOP/s (incl. pack)")
 
 
 if __name__ == "__main__":
