@@ -19,6 +19,8 @@
 // (stride 32 B, the two channel halves interleaved) -> conflict-free without padding.
 #include <stdlib.h>
 
+#include <utility>
+
 #include "ops.h"
 #include "slab_sum.h"
 
@@ -636,6 +638,230 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
                                              nullptr, relu);
 }
 
+// ------------------------------------------------------------------------ persistent variant with asynchronous staging
+// Cout = 16 forward layers at full resolution (16 -> 16, 32 -> 16).  Same tile, K-step order and epilogue as the kernel
+// above; what changes is how a workgroup's phases relate.  There, a chunk is  barrier | LDS writes | barrier | issue the next
+// loads | MFMAs | stores  in series (stamps: the MFMA phase is half of a wave's time) and only the partner workgroup on the
+// CU hides any of it.  Here the halo tile goes global -> LDS by DMA (buffer_load ... lds: no staging registers, no ds_write,
+// out-of-bounds pieces arrive as zeros from the buffer bounds check) into the OTHER of two LDS tiles while the MFMAs of the
+// current chunk run, with ONE barrier per chunk; the registers the staging freed hold all weight fragments (no weight reads
+// from LDS), and the fragment reads are a hand-pipelined stream (ring of 7, counted lgkmcnt waits).
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int NCH>
+struct DmaMma {
+    static constexpr int IY = 10, IX = 18, RS = IX * 32, PS = IY * IX * 32;
+    static constexpr int NFRAG = 70, PF = 6, NR = PF + 1;
+    const char *pA, *pB, *pH, *pI;
+    bf16x8 R[NR];
+    template <int I>
+    __device__ __forceinline__ bf16x8 fload() const {
+        if constexpr (I < 54) {
+            constexpr int dz = I / 18, k = I % 18;
+            if constexpr (k < 10) return *reinterpret_cast<const bf16x8*>(pA + (dz * IY + k) * RS);
+            else return *reinterpret_cast<const bf16x8*>(pB + (dz * IY + (k - 10)) * RS);
+        } else if constexpr (I < 62) {
+            return *reinterpret_cast<const bf16x8*>(pH + (I - 54) * RS);
+        } else {
+            return *reinterpret_cast<const bf16x8*>(pI + (I - 62) * RS);
+        }
+    }
+    template <int CH, int I, typename Side>
+    __device__ __forceinline__ void step(f32x4 (&acc)[8], const bf16x8 (&Wr)[NCH][14], Side& side) {
+        // one DMA piece of the next chunk every 7 fragments: spread under the MFMAs instead of a burst in front of them
+        if constexpr (I >= 2 && (I - 2) % 7 == 0 && (I - 2) / 7 < 9) side(std::integral_constant<int, (I - 2) / 7>{});
+        if constexpr (I + PF < NFRAG) R[(I + PF) % NR] = fload<I + PF>();
+        const bf16x8 f = R[I % NR];
+        if constexpr (I < 54) {
+            constexpr int dz = I / 18, k = I % 18;
+            if constexpr (k < 10) {
+                if constexpr (k < 8) acc[k] = mfma16(Wr[CH][dz * 4 + 0], f, acc[k]);
+                if constexpr (k >= 1 && k - 1 < 8) acc[k - 1] = mfma16(Wr[CH][dz * 4 + 1], f, acc[k - 1]);
+                if constexpr (k >= 2 && k - 2 < 8) acc[k - 2] = mfma16(Wr[CH][dz * 4 + 2], f, acc[k - 2]);
+            } else {
+                acc[k - 10] = mfma16(Wr[CH][dz * 4 + 3], f, acc[k - 10]);
+            }
+        } else if constexpr (I < 62) {
+            acc[I - 54] = mfma16(Wr[CH][12], f, acc[I - 54]);
+        } else {
+            acc[I - 62] = mfma16(Wr[CH][13], f, acc[I - 62]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int... Is>
+    __device__ __forceinline__ void prologue(std::integer_sequence<int, Is...>) { ((R[Is] = fload<Is>()), ...); }
+    template <int CH, typename Side, int... Is>
+    __device__ __forceinline__ void run(f32x4 (&acc)[8], const bf16x8 (&Wr)[NCH][14], Side& side, std::integer_sequence<int, Is...>) {
+        (step<CH, Is>(acc, Wr, side), ...);
+    }
+    template <int CH, typename Side>
+    __device__ __forceinline__ void chunk(f32x4 (&acc)[8], const bf16x8 (&Wr)[NCH][14], const char* tile, int laneOff, int g,
+                                          Side& side) {
+        pA = tile + laneOff + (g >> 1) * 32;                                   // dx = 0 | 1
+        pB = tile + laneOff + (g >> 1) * RS + 64;                              // dy = 0 | 1 at dx = 2
+        pH = tile + laneOff + (g >> 1) * PS + (2 * IX + 2) * 32;               // dz = 0 | 1 at (dy, dx) = (2, 2)
+        pI = tile + laneOff + 2 * PS + 2 * RS + 64;                            // (2, 2, 2) | pad
+        prologue(std::make_integer_sequence<int, PF>{});
+        __builtin_amdgcn_sched_barrier(0);
+        run<CH>(acc, Wr, side, std::make_integer_sequence<int, NFRAG>{});
+    }
+};
+
+constexpr int DMA_NIT = 9, DMA_TILE_BYTES = DMA_NIT * BLK * 16;      // 36 864 B per LDS tile (6*10*18 voxels * 32 B = 34 560 used)
+constexpr unsigned DMA_OOB = 0xffffff00u;                             // >= num_records: the bounds check returns zeros
+
+template <int NCH, bool STATS>
+__global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_dma_kernel(const bf16* __restrict__ x, int xcs,
+                                                                        const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                                        bf16* __restrict__ y, int ycs, int D, int H, int W,
+                                                                        int tilesZ, int tilesY, int tilesX, int ntiles,
+                                                                        float* __restrict__ part, Halves xh, Halves yh, int relu) {
+    constexpr int TZ = 4, TY = 8, TX = 16, IY = 10, IX = 18, MB = 8, NVOX = 6 * IY * IX;
+    extern __shared__ __attribute__((aligned(16))) char dma_lds[];
+    float (*red)[16][2] = reinterpret_cast<float (*)[16][2]>(dma_lds + 2 * DMA_TILE_BYTES);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int vn = lane & 15, g = lane >> 4;
+    const int laneOff = ((vn * 16 + (g & 1) * 8) * 2) + wave * (IY * IX * 32);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(x), (short)0, (int)DMA_OOB, 0x00020000);
+
+    // staging map, tile-invariant: byte offset of this thread's pieces relative to halo voxel (0,0,0), and their halo
+    // coordinates packed 12 bits each for the border tiles
+    unsigned relb[DMA_NIT];
+    unsigned pk[(DMA_NIT + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (DMA_NIT + 1) / 2; i++) pk[i] = 0;
+#pragma unroll
+    for (int it = 0; it < DMA_NIT; it++) {
+        int idx = threadIdx.x + it * BLK;
+        int vox = idx >> 1, half = idx & 1;
+        int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+        relb[it] = idx < NVOX * 2 ? (unsigned)((((iz * H + iy) * W + ix) * xcs + half * 8) * 2) : DMA_OOB;
+        if (iz > 7) iz = 7;
+        pk[it >> 1] |= (unsigned)(ix | (iy << 5) | (iz << 9)) << ((it & 1) * 16);
+    }
+    // all weight fragments stay in registers (ktap mode 1 pack: [chunk][14 K-steps][lane][8])
+    bf16x8 Wr[NCH][14];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+        for (int s_ = 0; s_ < 14; s_++) Wr[ch][s_] = *reinterpret_cast<const bf16x8*>(wp + ((int64_t)ch * 14 + s_) * 512 + lane * 8);
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bv[j] = bias ? bias[g * 4 + j] : 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+
+    auto tile_origin = [&](int tile, int& n, int& z0, int& y0, int& x0) {
+        int tz_ = tile % tilesZ; tile /= tilesZ;
+        int ty_ = tile % tilesY; tile /= tilesY;
+        int tx_ = tile % tilesX; n = tile / tilesX;
+        z0 = tz_ * TZ; y0 = ty_ * TY; x0 = tx_ * TX;
+    };
+    // DMA of (tile, chunk) into LDS tile `buf`: each wave-instruction lands 64 consecutive 16-byte pieces.  stage_prep
+    // computes the nine byte offsets (out of bounds -> DMA_OOB), stage_piece<it> issues one piece
+    unsigned soff[DMA_NIT];
+    char* sdst = dma_lds;
+    bool s_on = false;
+    auto stage_prep = [&](int tile, int chunk, int buf) {
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+        const int64_t base = ((((int64_t)n * D + (z0 - 1)) * H + (y0 - 1)) * W + (x0 - 1)) * xcs + chunk * 16 +
+                             (chunk >= xh.split ? xh.delta : 0);
+        const unsigned baseb = (unsigned)(base * 2);         // may wrap below zero for border tiles: only used where in bounds
+        const bool interior = z0 >= 1 && z0 + TZ + 1 <= D && y0 >= 1 && y0 + TY + 1 <= H && x0 >= 1 && x0 + TX + 1 <= W;
+        sdst = dma_lds + buf * DMA_TILE_BYTES + wave * 1024;
+#pragma unroll
+        for (int it = 0; it < DMA_NIT; it++) {
+            unsigned off = relb[it] == DMA_OOB ? DMA_OOB : baseb + relb[it];
+            if (!interior) {
+                unsigned c = pk[it >> 1] >> ((it & 1) * 16);
+                unsigned gz = (unsigned)(z0 - 1) + ((c >> 9) & 7u), gy = (unsigned)(y0 - 1) + ((c >> 5) & 15u),
+                         gx = (unsigned)(x0 - 1) + (c & 31u);
+                bool inb = gz < (unsigned)D && gy < (unsigned)H && gx < (unsigned)W;
+                off = inb ? off : DMA_OOB;
+            }
+            soff[it] = off;
+        }
+        s_on = true;
+    };
+    auto stage_piece = [&](auto itc) {
+        constexpr int it = decltype(itc)::value;
+        if (s_on) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(sdst + it * (BLK * 16)), 16, soff[it], 0, 0, 0);
+    };
+    auto stage_all = [&]() {
+        stage_piece(std::integral_constant<int, 0>{}); stage_piece(std::integral_constant<int, 1>{});
+        stage_piece(std::integral_constant<int, 2>{}); stage_piece(std::integral_constant<int, 3>{});
+        stage_piece(std::integral_constant<int, 4>{}); stage_piece(std::integral_constant<int, 5>{});
+        stage_piece(std::integral_constant<int, 6>{}); stage_piece(std::integral_constant<int, 7>{});
+        stage_piece(std::integral_constant<int, 8>{});
+        static_assert(DMA_NIT == 9, "stage_all issues nine pieces");
+    };
+
+    int tile;
+    {
+        int nwg = gridDim.x, bid = blockIdx.x, q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    int buf = 0;
+    if (tile < ntiles) { stage_prep(tile, 0, 0); stage_all(); }
+    DmaMma<NCH> mm;
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x4 acc[MB];
+#pragma unroll
+        for (int r = 0; r < MB; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto one_chunk = [&](auto chc) {
+            constexpr int ch = decltype(chc)::value;
+            // my pieces of the current tile have landed; after the barrier everyone's have, and everyone has finished
+            // reading the other tile (the previous chunk's MFMAs) -> it may be overwritten by the next DMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            s_on = false;
+            if (ch + 1 < NCH) stage_prep(tile, ch + 1, buf ^ 1);
+            else if (tile + (int)gridDim.x < ntiles) stage_prep(tile + gridDim.x, 0, buf ^ 1);
+            stage_all();
+            auto no_side = [](auto) {};
+            mm.template chunk<ch>(acc, Wr, dma_lds + buf * DMA_TILE_BYTES, laneOff, g, no_side);
+            buf ^= 1;
+        };
+        one_chunk(std::integral_constant<int, 0>{});
+        if constexpr (NCH > 1) one_chunk(std::integral_constant<int, NCH - 1>{});
+        static_assert(NCH <= 2, "one or two 16-channel chunks");
+        // ---- epilogue of this tile
+        int n, z0, y0, x0;
+        tile_origin(tile, n, z0, y0, x0);
+        int gz = z0 + wave, gx = x0 + vn;
+        bf16* yrow = y + ((((int64_t)n * D + gz) * H + y0) * W + gx) * ycs + g * 4 + (0 >= yh.split ? yh.delta : 0);
+        bool okzx = gz < D && gx < W;
+#pragma unroll
+        for (int r = 0; r < MB; r++) {
+            bool ok = okzx && (y0 + r) < H;
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = acc[r][j] + bv[j];
+                if (relu) v = fmaxf(v, 0.f);
+                o[j] = (bf16)v;
+                if (STATS) { float q = ok ? (float)o[j] : 0.f; s1[j] += q; s2[j] = fmaf(q, q, s2[j]); }
+            }
+            if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs) = o;
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float a = s1[j], b = s2[j];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (vn == 0) { red[wave][g * 4 + j][0] = a; red[wave][g * 4 + j][1] = b; }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32; idx += BLK) {
+            int k = idx & 1, chn = idx >> 1;
+            float v = (red[0][chn][k] + red[1][chn][k]) + (red[2][chn][k] + red[3][chn][k]);
+            part[((int64_t)blockIdx.x * 2 + k) * 16 + chn] = v;
+        }
+    }
+}
+
 constexpr int PERSIST_WGS = 512;
 inline bool persist_ok(int Cin, int Cout, Geo g) {
     // 16 -> 32 (two co blocks, 256 VGPRs): only worth it with >= 2 tiles per workgroup; the one-tile-per-workgroup
@@ -789,6 +1015,25 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
             if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu); \
             else conv3_mfma_persist_kernel<COB_, NCH_, false><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh, relu); \
         } while (0)
+        // Cout = 16: asynchronous-staging variant (the tensor must be addressable with 32-bit byte offsets)
+        // OFF by default: the kernels are 6-9 % faster, but with them in the step the part runs at 2350 instead of
+        // 2392 MHz (rocm-smi during bench.py, at LOWER package power) and the step gets 15-40 us slower
+        const bool dma = Cout == 16 && (Cin == 16 || Cin == 32) && getenv("MI3D_CONV_DMA") &&
+                         (size_t)g.M() * (size_t)(xh.on() ? 2 * xcs : xcs) * 2 < (size_t)DMA_OOB;
+        if (dma) {
+            size_t lds = 2 * (size_t)DMA_TILE_BYTES + 4 * 16 * 2 * sizeof(float);
+#define PD(NCH_)                                                                                                              \
+            do {                                                                                                              \
+                if (part) { MI3D_SET_MAX_LDS_ONCE((&conv3_mfma_persist_dma_kernel<NCH_, true>), lds);                         \
+                    conv3_mfma_persist_dma_kernel<NCH_, true><<<grid, BLK, lds, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu); } \
+                else { MI3D_SET_MAX_LDS_ONCE((&conv3_mfma_persist_dma_kernel<NCH_, false>), lds);                             \
+                    conv3_mfma_persist_dma_kernel<NCH_, false><<<grid, BLK, lds, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh, relu); } \
+            } while (0)
+            if (Cin == 16) PD(1); else PD(2);
+#undef PD
+            MI3D_LAUNCH_CHECK();
+            return 0;
+        }
         if (Cin == 16 && Cout == 16) PK(1, 1);
         else if (Cin == 32) PK(1, 2);
         else PK(2, 1);

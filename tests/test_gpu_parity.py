@@ -500,6 +500,35 @@ def test_layout_and_kernel_choices_are_invisible(monkeypatch):
     assert relerr(vb, va) < 0.1
 
 
+def test_conv3_async_staging_variant_is_bit_identical(monkeypatch):
+    """MI3D_CONV_DMA=1: the Cout = 16 full-resolution forward convs stage their halo tiles global -> LDS by DMA into a second
+    LDS tile (one barrier per chunk, all weights in registers).  Same K-step order and fp32 accumulation order as the default
+    kernel -> the bf16 outputs are identical bit for bit, ragged borders (zero fill through the buffer bounds check) included."""
+    from multimodal_segmentation_project_amd import _lib
+    from multimodal_segmentation_project_amd._lib import call, ptr
+    for (n, cin, d, h, w) in [(2, 16, 8, 16, 32), (1, 32, 6, 17, 35), (1, 16, 12, 24, 48)]:
+        cout = 16
+        g = torch.Generator(device=DEV).manual_seed(n + cin + w)
+        x = torch.randn(n, d, h, w, cin, device=DEV, generator=g).bfloat16()
+        wgt = torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) * 0.1
+        b = torch.randn(cout, device=DEV, generator=g)
+        wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, h, w)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        outs = []
+        for on in (False, True):
+            if on:
+                monkeypatch.setenv("MI3D_CONV_DMA", "1")
+            else:
+                monkeypatch.delenv("MI3D_CONV_DMA", raising=False)
+            y = torch.full((n, d, h, w, cout), float("nan"), device=DEV, dtype=torch.bfloat16)
+            call("mi3d_conv3_forward", 1, 1, ptr(x), cin, cin, ptr(wgt), ptr(b), ptr(y), cout, cout, n, d, h, w, ptr(ws), wsb, None)
+            torch.cuda.synchronize()
+            outs.append(y)
+        assert torch.isfinite(outs[1].float()).all()
+        assert torch.equal(outs[0], outs[1]), (n, cin, d, h, w)
+    monkeypatch.delenv("MI3D_CONV_DMA", raising=False)
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 16, 5, 9, 17), (2, 32, 16, 6, 17, 35), (1, 16, 32, 4, 16, 48),
                                    (1, 64, 32, 4, 8, 8), (1, 32, 64, 3, 6, 6), (1, 16, 16, 8, 16, 32)])
 def test_conv3_mfma_vs_c_oracle(orc, shape):
