@@ -8,8 +8,8 @@
 
 One JSON line on rank 0.  `value` = whole-job volumes/s (global batch * K / max-over-ranks time), inputs resident
 in HBM before timing.  `roofline` = the dominant kernel (measured live with HIP events on its own launches, same
-shapes as in the step) against the 8 TB/s HBM peak; `cpu_baseline` = the oracle's vanilla-torch restatement timed
-on the host cores (rank 0, N=1 only, bounded sample).
+shapes as in the step; the launch with the largest time per step) against the 8 TB/s HBM peak; `cpu_baseline` = the oracle's
+vanilla-torch restatement timed on the host cores (rank 0, N=1 only, bounded sample, 16 and 8 threads).
 """
 import argparse
 import json
@@ -34,8 +34,10 @@ def synth(n, s, seed):
     return x, y
 
 
-def cpu_baseline(size, batch, max_seconds=30.0):
-    """The oracle (oracle/torch_ref.py: vanilla torch.nn.functional restatement, fp32) on the host cores."""
+def cpu_baseline(size, batch, max_seconds=24.0):
+    """The oracle (oracle/torch_ref.py: vanilla torch.nn.functional restatement, fp32, validated against the reference-
+    generated fixtures in tests/golden by tests/test_oracle_cpu.py) on the host cores, at the two thread counts BASELINE.md
+    section 4 asks for: the box's CPU share (16 on a 1-GPU box) and 8 (the survey container's probe).  `value` is the faster."""
     from oracle import torch_ref
     import multimodal_segmentation_project_amd as mi
     torch.manual_seed(0)
@@ -50,30 +52,58 @@ def cpu_baseline(size, batch, max_seconds=30.0):
     except AttributeError:
         avail = os.cpu_count() or 1
     # a 1-GPU box exposes all host cores but grants a 16-core share (oversubscribing 256 threads ran 14x slower)
-    cores = min(avail, int(os.environ.get("MI3D_CPU_BASELINE_THREADS", "16")))
-    torch.set_num_threads(cores)
-    times = []
-    t_all = time.time()
-    for it in range(4):
-        t0 = time.time()
-        logits, _, _ = torch_ref.unet3d_forward(sd, x, train=True)
-        loss = torch_ref.seg_loss(logits, y, "combined")
-        loss.backward()
-        for v in sd.values():
-            v.grad = None
-        dt = time.time() - t0
-        if it > 0:
-            times.append(dt)
-        if time.time() - t_all > max_seconds and times:
-            break
-    med = sorted(times)[len(times) // 2]
-    return {"value": batch / med, "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} fwd+loss+bwd steps of UNet3D {size}^3 N={batch} fp32 after 1 warm-up (median)"}
+    share = min(avail, int(os.environ.get("MI3D_CPU_BASELINE_THREADS", "16")))
+    runs = {}
+    for cores in sorted({share, min(share, 8)}, reverse=True):
+        torch.set_num_threads(cores)
+        times = []
+        t_all = time.time()
+        for it in range(4):
+            t0 = time.time()
+            logits, _, _ = torch_ref.unet3d_forward(sd, x, train=True)
+            loss = torch_ref.seg_loss(logits, y, "combined")
+            loss.backward()
+            for v in sd.values():
+                v.grad = None
+            dt = time.time() - t0
+            if it > 0:
+                times.append(dt)
+            if time.time() - t_all > max_seconds / 2 and times:
+                break
+        med = sorted(times)[len(times) // 2]
+        runs[cores] = (batch / med, len(times))
+    best = max(runs, key=lambda c: runs[c][0])
+    return {"value": runs[best][0], "unit": "volumes/s", "cores": best, "kind": "port",
+            "by_threads": {str(c): round(v[0], 4) for c, v in runs.items()},
+            "validated_against": "tests/golden (fixtures produced by executing the reference; tests/test_oracle_cpu.py)",
+            "sample": f"{runs[best][1]} fwd+loss+bwd steps of UNet3D {size}^3 N={batch} fp32 after 1 warm-up (median), per thread count"}
+
+
+def _kernel_traffic(kernel_substr, ms):
+    """HBM bytes per launch of the named kernel from the committed PMC passes of this build (tools/collect_profiles.sh ->
+    profiles/roofline_kernel_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of the whole step,
+    corrected by tools/pmc_traffic.py).  A PMC pass cannot run inside this process; the committed value is reported only
+    while the kernel still takes the time it took when the counters were collected (else null, not a stale number)."""
+    tf = os.path.join(ROOT, "profiles", "roofline_kernel_traffic.json")
+    try:
+        rec = json.load(open(tf))
+        if kernel_substr not in rec.get("kernel", ""):
+            return None
+        ref_ms = rec.get("ms_per_launch_when_measured")
+        if ref_ms and abs(ms - ref_ms) > 0.10 * ref_ms:
+            return None
+        return rec.get("hbm_bytes_per_launch")
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def roofline_dominant(size, batch, dtype_code, iters=10):
-    """Dominant kernel = the 3x3x3 conv of decoder.3.conv0 (32->16 @ full resolution): forward launch measured with
-    HIP events on the stream it runs on.  Algorithmic bytes = read x once + write y once (+ weights)."""
+    """Dominant kernel = the launch with the largest time per step (profiles/rNN_step_timeline.txt): the fused backward of
+    decoder.3.conv0 (32 -> 16 channels at full resolution), conv3_bwd_fused_persist_kernel<2,1> = input gradient + weight
+    gradient of the layer in one launch.  Timed live with HIP events recorded tightly around THAT kernel on the stream it is
+    launched on (mi3d_time_next_conv3_bwd_kernel; the per-operator call also launches a weight pack and a slab sum, which
+    stay outside the events).  Algorithmic bytes per launch = read dy once + read x once + write dx once (+ dW):
+    M * (Cout + Cin + Cin) * 2 B -- both products of the layer share one read of dy in the ideal kernel."""
     import ctypes as C
     from multimodal_segmentation_project_amd import _lib
     from multimodal_segmentation_project_amd._lib import call, ptr, stream_ptr
@@ -83,44 +113,50 @@ def roofline_dominant(size, batch, dtype_code, iters=10):
     T = torch.bfloat16 if dtype_code == 1 else torch.float32
     n, d = batch, size
     x = torch.randn((n, d, d, d, cin), device=dev).to(T)
+    dy = torch.randn((n, d, d, d, cout), device=dev).to(T)
     w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
-    b = torch.zeros(cout, device=dev)
-    y = torch.empty((n, d, d, d, cout), device=dev, dtype=T)
+    dx = torch.empty_like(x)
+    dW, db = torch.empty_like(w), torch.empty(cout, device=dev)
     wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, d, d)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     s = stream_ptr()
+
+    def once():
+        call("mi3d_conv3_backward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(dy), cout, cout, ptr(dx), cin, ptr(dW),
+             ptr(db), 0, n, d, d, d, ptr(ws), wsb, s)
     for _ in range(2):
-        call("mi3d_conv3_forward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(b), ptr(y), cout, cout, n, d, d, d,
-             ptr(ws), wsb, s)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        call("mi3d_conv3_forward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(b), ptr(y), cout, cout, n, d, d, d,
-             ptr(ws), wsb, s)
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+        once()
     vox = n * d ** 3
-    algo_bytes = vox * (cin + cout) * esz + cout * cin * 27 * 4
+    algo_bytes = vox * (cout + cin + cin) * esz + cout * cin * 27 * 4
+    kernel = "conv3_bwd_fused_persist_kernel<2, 1>"
+    if dtype_code == 1:
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        call("mi3d_timing_event_create", C.byref(e0))
+        call("mi3d_timing_event_create", C.byref(e1))
+        tot = 0.0
+        for _ in range(iters):
+            call("mi3d_time_next_conv3_bwd_kernel", e0, e1)
+            once()
+            t = C.c_float()
+            call("mi3d_event_elapsed_ms", e0, e1, C.byref(t))
+            tot += t.value
+        ms = tot / iters
+        call("mi3d_event_destroy", e0)
+        call("mi3d_event_destroy", e1)
+    else:       # exact fp32 path: separate direct kernels, the whole operator call is timed
+        kernel = "conv3 direct dgrad + wgrad (fp32 path, whole operator call)"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            once()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / iters
     achieved = algo_bytes / (ms * 1e-3) / 1e9
-    # HBM traffic per launch from the committed PMC passes of this same loop (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs of `bench.py --roofline-only`, corrected by tools/pmc_traffic.py); null if the file is absent
-    # (a PMC pass cannot run inside this process; the committed value is only reported while the kernel still takes the time
-    # it took when the counters were collected: a changed kernel yields null instead of a stale number)
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "roofline_kernel_traffic.json")
-    if os.path.exists(tf):
-        try:
-            rec = json.load(open(tf))
-            traffic = rec.get(f"{size}^3xN{batch}_{'bf16' if dtype_code == 1 else 'fp32'}")
-            ref_ms = rec.get("_ms_per_launch_when_measured")
-            if traffic is not None and ref_ms and abs(ms - ref_ms) > 0.10 * ref_ms:
-                traffic = None
-        except Exception:   # noqa: BLE001
-            traffic = None
-    return {"bound": "hbm", "kernel": "conv3 fwd 32->16 (decoder.3.conv0)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "ms_per_launch": ms,
-            "algorithmic_bytes_per_launch": algo_bytes}
+    return {"bound": "hbm", "kernel": kernel + " = conv3 bwd 32->16 (decoder.3.conv0: input gradient + weight gradient)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": _kernel_traffic(kernel, ms), "ms_per_launch": ms, "algorithmic_bytes_per_launch": algo_bytes,
+            "flops_per_launch": 2 * 2 * 27 * cin * cout * vox}
 
 
 def main():
@@ -170,9 +206,9 @@ def main():
         return
     torch.manual_seed(0)
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    # one hipGraph per step at world 1.  With gradient exchange (world > 1) the step is launched eagerly: the all-reduces
-    # cut the graph into 7 segments, and eager launches measured faster than segmented replay (2.51 vs
-    # 2.56 ms on the 1-rank RCCL path; eager == full graph without communication); --graph-segments forces the segments
+    # one hipGraph per step at world 1.  With gradient exchange (world > 1) the step is launched eagerly: the two exchanges
+    # (dp.bucket_ranges) cut the graph into segments, and eager launches measured faster than segmented replay (DESIGN.md §6:
+    # 2.447 vs 2.517 ms on the 1-rank RCCL path; eager == full graph without communication); --graph-segments forces the segments
     use_graph = (not a.no_graph) and ((world == 1 and not a.force_comm) or a.graph_segments)
     x, y = synth(a.batch, a.size, 1234 + rank)
     if a.workload == "dann":

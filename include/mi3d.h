@@ -96,6 +96,13 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
  * forked/joined with the events so the call stays stream-ordered for the caller and hipGraph-capturable. */
 int mi3d_event_create(void** event_out);
 int mi3d_event_destroy(void* event);
+/* Measurement hooks (bench.py `roofline`: HIP events around ONE kernel on the stream it is launched on).
+ * mi3d_time_next_conv3_bwd_kernel: the next fused conv backward launch (mi3d_conv3_backward / mi3d_unet_backward on the calling
+ * thread) records start/stop -- timing events from mi3d_timing_event_create -- tightly around its kernel; one-shot.
+ * mi3d_event_elapsed_ms synchronises on `stop`. */
+int mi3d_timing_event_create(void** event_out);
+int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event);
+int mi3d_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out);
 /* params-table index ranges whose gradients segment `seg` produces: ranges = {first0, last0, first1, last1}
  * (half-open; the second range is the segment's upconv for decoder segments, otherwise {-1,-1}) */
 int mi3d_unet_segment_params(const mi3d_unet_desc* d, int seg, int* ranges);
@@ -246,6 +253,12 @@ int mi3d_bn_relu_drop_forward(int dtype, const void* y, int ycs, int C, int64_t 
 int mi3d_bn_relu_drop_backward(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
                                const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
                                int accumulate, void* workspace, void* stream);
+/* the second half of an encoder block as the training step runs it (unet.py:16-18 then :71): train-mode BatchNorm3d + ReLU +
+ * Dropout3d writing z AND pooled = MaxPool3d(2,2)(z) in one pass.  Even D, H, W; pooled [N][D/2][H/2][W/2][C], stride pcs */
+int mi3d_bn_relu_drop_pool_forward(int dtype, const void* y, int ycs, int C, int N, int D, int H, int W, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                   float momentum, float eps, const float* drop, void* z, int zcs, void* pooled, int pcs,
+                                   float* stat, void* workspace, void* stream);
 int mi3d_maxpool2_forward(int dtype, const void* z, int zcs, int C, int N, int D, int H, int W, void* p, int pcs,
                           void* stream);
 int mi3d_maxpool2_backward(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs,
@@ -257,6 +270,15 @@ int mi3d_upconv2_forward(int dtype, const void* x, int xcs, int Cin, const float
 int mi3d_upconv2_backward(int dtype, const void* x, int xcs, int Cin, const float* w, const void* gy, int gycs, int Cout,
                           void* dx, int dxcs, float* dW, float* db, int accumulate, int N, int D, int H, int W,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* final nn.Conv3d(C0, n_classes, 1) unet.py:62,87.  z: channels-last `dtype` [N][V][Cin] (stride zcs); w (Cout,Cin,1,1,1) float;
+ * logits / dlogits: NCDHW float (the API layout).  backward: dz (channels-last, stride dzcs), dW (Cout,Cin), db (Cout) float;
+ * workspace: mi3d_conv1_workspace_bytes.  The bf16 path runs the MFMA kernels of the training step. */
+size_t mi3d_conv1_workspace_bytes(int Cin, int Cout);
+int mi3d_conv1_forward(int dtype, const void* z, int zcs, int Cin, const float* w, const float* bias, float* logits, int Cout,
+                       int N, int64_t V, void* stream);
+int mi3d_conv1_backward(int dtype, const void* z, int zcs, int Cin, const float* w, const float* dlogits, int Cout, void* dz,
+                        int dzcs, float* dW, float* db, int accumulate, int N, int64_t V, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* layout helpers: NCDHW float <-> channels-last `dtype` */
 int mi3d_ncdhw_to_ndhwc(int dtype, const float* src, void* dst, int dcs, int C, int N, int64_t V, void* stream);
 int mi3d_ndhwc_to_ncdhw(int dtype, const void* src, int scs, float* dst, int C, int N, int64_t V, void* stream);

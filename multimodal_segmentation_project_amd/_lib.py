@@ -55,6 +55,9 @@ _SIGS = {
     "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp]),
     "mi3d_event_create": (i32, [C.POINTER(vp)]),
     "mi3d_event_destroy": (i32, [vp]),
+    "mi3d_timing_event_create": (i32, [C.POINTER(vp)]),
+    "mi3d_time_next_conv3_bwd_kernel": (i32, [vp, vp]),
+    "mi3d_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
     "mi3d_seg_loss_workspace_bytes": (sz, [i32]),
     "mi3d_seg_loss_forward": (i32, [vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, vp]),
     "mi3d_seg_loss_backward": (i32, [vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, vp]),
@@ -84,6 +87,11 @@ _SIGS = {
     "mi3d_bn_relu_drop_forward": (i32, [i32, vp, i32, i32, i64, i64, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, i32,
                                         vp, vp, vp]),
     "mi3d_bn_relu_drop_backward": (i32, [i32, vp, i32, vp, i32, i32, i64, i64, vp, vp, vp, i32, vp, vp, i32, vp, vp]),
+    "mi3d_bn_relu_drop_pool_forward": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, i32,
+                                             vp, i32, vp, vp, vp]),
+    "mi3d_conv1_workspace_bytes": (sz, [i32, i32]),
+    "mi3d_conv1_forward": (i32, [i32, vp, i32, i32, vp, vp, vp, i32, i32, i64, vp]),
+    "mi3d_conv1_backward": (i32, [i32, vp, i32, i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i64, vp, sz, vp]),
     "mi3d_maxpool2_forward": (i32, [i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mi3d_maxpool2_backward": (i32, [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mi3d_upconv2_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),

@@ -188,6 +188,35 @@ int mi3d_bn_relu_drop_backward(int dtype, const void* dz, int dzcs, const void* 
     return bn_bwd(dtype, dz, dzcs, y, ycs, C, M, V, stat, drop, dy, dycs, dgamma, dbeta, accumulate, (float*)workspace,
                   (hipStream_t)stream);
 }
+int mi3d_bn_relu_drop_pool_forward(int dtype, const void* y, int ycs, int C, int N, int D, int H, int W, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                   float momentum, float eps, const float* drop, void* z, int zcs, void* pooled, int pcs,
+                                   float* stat, void* workspace, void* stream) {
+    MI3D_CHECK_ARG(y && gamma && beta && z && pooled && stat && workspace, "mi3d_bn_relu_drop_pool_forward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    Geo g{N, D, H, W};
+    int small_rows = 0;
+    MI3D_TRY(bn_train_stats(dtype, y, ycs, C, g.M(), gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                            stat, (float*)workspace, s, &small_rows));
+    BnSmall sm{(const float*)workspace, small_rows, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps};
+    return bn_apply_relu_drop_pool(dtype, y, ycs, C, g, stat, drop, z, zcs, pooled, pcs, s, small_rows > 0 ? &sm : nullptr);
+}
+size_t mi3d_conv1_workspace_bytes(int Cin, int Cout) { return conv1_bwd_ws_floats(Cin, Cout) * sizeof(float); }
+int mi3d_conv1_forward(int dtype, const void* z, int zcs, int Cin, const float* w, const float* bias, float* logits, int Cout,
+                       int N, int64_t V, void* stream) {
+    MI3D_CHECK_ARG(z && w && logits, "mi3d_conv1_forward: null pointer");
+    MI3D_CHECK_ARG(dtype == MI3D_F32 || dtype == MI3D_BF16, "mi3d_conv1_forward: bad dtype %d", dtype);
+    return conv1_fwd(dtype, z, zcs, Cin, w, bias, logits, Cout, N, V, (hipStream_t)stream);
+}
+int mi3d_conv1_backward(int dtype, const void* z, int zcs, int Cin, const float* w, const float* dlogits, int Cout, void* dz,
+                        int dzcs, float* dW, float* db, int accumulate, int N, int64_t V, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    MI3D_CHECK_ARG(z && w && dlogits && dz && workspace, "mi3d_conv1_backward: null pointer");
+    MI3D_CHECK_ARG(dtype == MI3D_F32 || dtype == MI3D_BF16, "mi3d_conv1_backward: bad dtype %d", dtype);
+    MI3D_CHECK_ARG(workspace_bytes >= mi3d_conv1_workspace_bytes(Cin, Cout), "mi3d_conv1_backward: workspace too small");
+    return conv1_bwd(dtype, z, zcs, Cin, w, dlogits, Cout, dz, dzcs, dW, db, accumulate, (float*)workspace, N, V,
+                     (hipStream_t)stream);
+}
 int mi3d_maxpool2_forward(int dtype, const void* z, int zcs, int C, int N, int D, int H, int W, void* p, int pcs,
                           void* stream) {
     MI3D_CHECK_ARG(z && p, "mi3d_maxpool2_forward: null pointer");
@@ -249,6 +278,19 @@ int mi3d_event_create(void** event_out) {
     hipEvent_t e;
     MI3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     *event_out = (void*)e;
+    return 0;
+}
+int mi3d_timing_event_create(void** event_out) {
+    MI3D_CHECK_ARG(event_out, "mi3d_timing_event_create: null output");
+    hipEvent_t e;
+    MI3D_HIP(hipEventCreate(&e));
+    *event_out = (void*)e;
+    return 0;
+}
+int mi3d_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out) {
+    MI3D_CHECK_ARG(start_event && stop_event && ms_out, "mi3d_event_elapsed_ms: null argument");
+    MI3D_HIP(hipEventSynchronize((hipEvent_t)stop_event));
+    MI3D_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)start_event, (hipEvent_t)stop_event));
     return 0;
 }
 int mi3d_event_destroy(void* event) {

@@ -19,6 +19,8 @@
 // (stride 32 B, the two channel halves interleaved) -> conflict-free without padding.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include <utility>
 
 #include "ops.h"
@@ -1650,6 +1652,13 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     return wgrad_slab_sum(ws, c.nsb, Cin, Cout, dW, db, accumulate, s, pend);
 }
 
+static thread_local hipEvent_t g_time_ev[2] = {nullptr, nullptr};
+extern "C" int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event) {
+    g_time_ev[0] = (hipEvent_t)start_event;
+    g_time_ev[1] = (hipEvent_t)stop_event;
+    return 0;
+}
+
 // full-resolution layers: dgrad on the persistent body (Cout -> Cin must be one of its shapes)
 bool conv3_mfma_bwd_fused_persist_ok(int Cin, int Cout, int xcs, int dycs, Geo g) {
     return persist_ok(Cout, Cin, g) && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && !getenv("MI3D_NO_FUSED_BWD") &&
@@ -1680,12 +1689,18 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     unsigned nblk = (unsigned)(2 * half);
     // dgrad conv Cout -> Cin: persistent shapes (16,16): <1,1>, (32->16): <1,2>, (16->32): <2,1>
     size_t ldsw = (size_t)(WNV + WNH) * 32;
+    // measurement hook (mi3d_time_next_conv3_bwd_kernel): one-shot HIP events tightly around this kernel
+    hipEvent_t tev0 = g_time_ev[0], tev1 = g_time_ev[1];
+    g_time_ev[0] = g_time_ev[1] = nullptr;
 #define FP(COB_, NCH_)                                                                                                        \
     do {                                                                                                                      \
         size_t ldsp = (size_t)(6 * 10 * 18 * 16 + NCH_ * 14 * COB_ * 512) * 2 + 4 * COB_ * 16 * 2 * 4;                        \
         size_t lds = ldsp > ldsw ? ldsp : ldsw;                                                                               \
         MI3D_SET_MAX_LDS_ONCE((&conv3_bwd_fused_persist_kernel<COB_, NCH_>), lds);                                            \
-        conv3_bwd_fused_persist_kernel<COB_, NCH_><<<nblk, BLK, lds, s>>>(a);                                                   \
+        if (tev0 && tev1)                                                                                                     \
+            hipExtLaunchKernelGGL((conv3_bwd_fused_persist_kernel<COB_, NCH_>), dim3(nblk), dim3(BLK), lds, s, tev0, tev1, 0, a); \
+        else                                                                                                                  \
+            conv3_bwd_fused_persist_kernel<COB_, NCH_><<<nblk, BLK, lds, s>>>(a);                                               \
     } while (0)
     if (Cout == 16 && Cin == 16) FP(1, 1);
     else if (Cout == 32) FP(1, 2);

@@ -12,12 +12,13 @@ Design (MI355X-first, not a DDP translation):
   * parameters, gradients and AdamW moments live in flat fp32 arenas (22.6 MB each); nn.Parameters are views, so
     state_dict()/load_state_dict() keep working, while the optimizer is ONE kernel and gradient all-reduce operates
     on contiguous arena ranges (no bucket copy-in/copy-out).
-  * backward runs as runs of segments; after the decoder, the bottleneck and encoder.L-1 segments the finished arena
-    range is all-reduced on a side stream (RCCL over xGMI) while the remaining, bandwidth-heavy full-resolution encoder
-    backward runs (82 % of gradient bytes are ready mid-backward).  The four scalar gathers of the reference
-    (C4) are one 4-float all-reduce launched right after the loss kernel, hidden under the whole backward.
-  * a step is captured into hipGraphs: ONE graph at world 1; at world > 1 one graph per comm-free run of kernels with
-    the all-reduces launched between them (RCCL calls stay outside the graphs).
+  * backward runs as runs of segments with TWO exchanges by default (dp.bucket_ranges): after encoder.L-1's segment the
+    arena range [encoder.L-1 .. final_conv] (97 % of the gradient bytes) is all-reduced on a side stream (RCCL over xGMI)
+    while the bandwidth-heavy encoder.L-2..0 backward runs; [encoder.0..L-2] follows at the end (MI3D_FINE_BUCKETS=1: four
+    readiness-ordered buckets, measured slower).  The four scalar gathers of the reference (C4) are one 4-float all-reduce
+    that rides on the first exchange.
+  * a step is captured into hipGraphs: ONE graph at world 1; at world > 1 the step is launched eagerly (or, on request, as
+    one graph per comm-free run of kernels with the all-reduces between them: RCCL calls stay outside the graphs).
   * BatchNorm statistics are per-GPU local (DDP + BatchNorm3d semantics); the per-forward buffer broadcast of DDP
      is replaced by `sync_buffers()` before eval/checkpoint.
   * no host synchronisation inside step(); results are device tensors.
@@ -189,12 +190,20 @@ class _StepBase:
     def _variant(self):
         return (self.micro % self.accum == 0, (self.micro + 1) % self.accum == 0)
 
-    def _run(self, st):
+    def _run(self, st, last_batch=False):
+        """last_batch: the final batch of an epoch.  The reference's loaders are accelerator.prepare()'d (train_unet.py:384),
+        so accelerate's accumulate() forces gradient sync + optimizer.step on the LAST batch of every epoch and restarts its
+        step count (GradientState.end_of_dataloader; train_dann.py:287 does the same by hand): the micro-step becomes a
+        boundary whatever its position in the window, and the next epoch starts a fresh window."""
         self._check_mode()
         variant = self._variant()
+        bump = 1
+        if last_batch and not variant[1]:
+            variant = (variant[0], True)
+            bump = self.accum - (self.micro % self.accum)
         if not self.use_graph:
             self._enqueue(st, variant, lambda fn: fn())
-            self.micro += 1
+            self.micro += bump
             return
         gr = st["graphs"]
         hyper = self._hyper()
@@ -208,7 +217,7 @@ class _StepBase:
             call("mi3d_graph_launch", g, stream_ptr())
             if fn is not None:
                 fn()
-        self.micro += 1
+        self.micro += bump
 
     def _mutable_state(self):
         """Tensors a step execution modifies (snapshot/restore around the capture warm-up)."""
@@ -458,20 +467,22 @@ class TrainStep(_StepBase):
         if boundary:
             self._adamw(self.arena, st["opt_ranges"], self._hyper(), s)
 
-    def step(self, images, labels):
+    def step(self, images, labels, last_batch=False):
         """One micro-step on (images (N,Cin,D,H,W) float, labels (N,1,D,H,W) int64).  Returns a device float32[4]
-        tensor {loss, iou, dice, acc} (already averaged over ranks when world > 1)."""
+        tensor {loss, iou, dice, acc} (already averaged over ranks when world > 1).
+        last_batch=True on the final batch of an epoch: the optimizer steps there even inside an accumulation window and
+        the next epoch starts a new window, as accelerate does for the reference's prepared loaders (see _run)."""
         st = self._prepare(images)
         st["x"].copy_(images, non_blocking=True)
         st["y"].copy_(labels.reshape(st["y"].shape), non_blocking=True)
-        return self.step_static()
+        return self.step_static(last_batch=last_batch)
 
-    def step_static(self):
+    def step_static(self, last_batch=False):
         """Run on the data already resident in the static buffers (bench path: inputs in HBM when timing starts)."""
         st = self._static
         if st is None:
             raise Mi3dError("step_static() before any step()/load_batch()")
-        self._run(st)
+        self._run(st, last_batch=last_batch)
         return st["metrics"]
 
     def load_batch(self, images, labels):
@@ -484,7 +495,10 @@ class TrainStep(_StepBase):
         """model.eval() forward + loss + metrics (train_unet.py:259-305: the TRAINING loss_fn; distill_unet.py:136-160:
         combined_loss), averaged over ranks like the reference's gather().mean(); returns device float32[4].  Has its own
         static state: a validation batch of another shape (the reference validates with batch 1) does not disturb the
-        captured training graph."""
+        captured training graph.  Under data parallelism rank 0's BatchNorm buffers are broadcast first: DDP broadcasts them at
+        every forward, so the reference validates with rank 0's running statistics on every rank."""
+        if self.do_comm:
+            self.sync_buffers()
         st = self._prepare(images, mode="eval")
         st["x"].copy_(images)
         st["y"].copy_(labels.reshape(st["y"].shape))
@@ -722,18 +736,8 @@ class DannStep(_StepBase):
         st = self._static
         if st is None:
             raise Mi3dError("step_static() before any step()/load_batch()")
-        if last_batch and (self.micro + 1) % self.accum != 0:
-            # force an optimizer step on this micro-batch, then start a fresh accumulation window
-            first = self.micro % self.accum == 0
-            if self.use_graph:
-                raise Mi3dError("last_batch with a partial accumulation window is not graph-captured; use use_graph=False")
-            self._check_mode()
-            self._enqueue(st, (first, True), lambda fn: fn())
-            self.micro += self.accum - (self.micro % self.accum)
-        else:
-            self._run(st)
-        out = st["metrics"]
-        return out
+        self._run(st, last_batch=last_batch)       # a partial window on the last batch: the (first, True) variant (captured like the others)
+        return st["metrics"]
 
     @torch.no_grad()
     def evaluate(self, images, labels):

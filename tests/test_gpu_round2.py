@@ -312,6 +312,9 @@ def test_reference_accumulation_quirk_and_evaluate(golden):
             if quirk and i == 1:      # after the first window: gradient = grad(second micro-batch)/2 at the initial parameters
                 np.testing.assert_allclose(torch.stack(outs).mean(0).numpy(), g["accum_first/result"], rtol=2e-4)
                 check_summary(g, "accum_first/", model, True, bn_tol=2e-4)
+            if i == 1:                # the gradient the first optimizer step consumed (AdamW leaves arena.g untouched)
+                ts.g_first = {k: ts.arena.g[o:o + p.numel()].reshape(p.shape).cpu().clone()
+                              for (k, p), o in zip(model.named_parameters(), ts.arena.offsets)}
         return model, ts, torch.stack(outs)
 
     model, ts, outs = run(True)
@@ -338,15 +341,20 @@ def test_reference_accumulation_quirk_and_evaluate(golden):
     model_b, ts_b, _ = run(False)
     torch.manual_seed(0)
     sd0 = {k: v.detach().clone() for k, v in mi.UNet3D(1, 4, dropout_rate=0.0).state_dict().items()}
-    ref_sd, _, _ = torch_ref.train_loop(sd0, batches, accum=2, zero_grad_quirk=False)
-    ref_q, _, _ = torch_ref.train_loop(sd0, batches, accum=2, zero_grad_quirk=True)
+    # PRE-update gradients of the first window, both routes, against the oracle's loop at the initial parameters: the default
+    # route accumulates (g1 + g2)/2, the quirk route applies g2/2 (AdamW's first step is sign-like, so parameter displacements
+    # cannot be compared tightly -- the gradients can)
+    _, _, ref_acc = torch_ref.train_loop(sd0, batches[:2], accum=2, zero_grad_quirk=False)
+    _, _, ref_qk = torch_ref.train_loop(sd0, batches[:2], accum=2, zero_grad_quirk=True)
+    for k, ra in ref_acc.items():
+        if float(ra.double().norm()) < 1e-6 or k.endswith("double_conv.0.bias") or k.endswith("double_conv.4.bias"):
+            continue            # conv bias in front of train-mode BN: analytically zero
+        assert relerr(ts_b.g_first[k], ra) < FP32_GRAD_TOL, (k, relerr(ts_b.g_first[k], ra))
+        assert relerr(ts.g_first[k], ref_qk[k]) < FP32_GRAD_TOL, (k, relerr(ts.g_first[k], ref_qk[k]))
+    k = "decoder.3.double_conv.0.weight"
+    assert relerr(ts_b.g_first[k], ts.g_first[k]) > 0.1             # ... and the two routes really differ
     sdb = model_b.state_dict()
-    for k in ("encoder.0.double_conv.4.weight", "decoder.3.double_conv.0.weight", "final_conv.weight", "upconvs.1.weight"):
-        step_b = (sdb[k].cpu() - sd0[k]).double()
-        step_ref = (ref_sd[k] - sd0[k]).double()
-        assert relerr(step_b, step_ref) < 0.15, k                    # AdamW steps (sign-like): compare the displacement
-        assert relerr((sd[k].cpu() - sd0[k]).double(), (ref_q[k] - sd0[k]).double()) < 0.15, k
-        assert relerr(step_b, (sd[k].cpu() - sd0[k]).double()) > 0.3, k
+    assert relerr((sdb[k].cpu() - sd0[k]).double(), (sd[k].cpu() - sd0[k]).double()) > 0.3
 
 
 def test_autocast_dispatch():

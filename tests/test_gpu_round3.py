@@ -1,0 +1,271 @@
+"""Round-3 GPU parity tests (through the C ABI): the bf16 VEC=8 elementwise kernels and the 1x1x1 head that the 96^3 step
+actually launches, pinned per operator against the C oracle, and the remaining kernel-route switches at the headline shape.
+
+Technique (as for the conv kernels in round 2): inputs are small DYADIC numbers that bf16 holds exactly, so that
+  * integer-like sums (dbeta, the head's dW / db, the head's logits) are exact in fp32 whatever the summation order -> they are
+    compared with `atol ~ 0`;
+  * values that pass through invstd (not dyadic) are compared with the oracle's double-precision result to fp32 roundoff, and
+    stored bf16 tensors to HALF A bf16 ULP of it (2^-9 relative: the kernels round an fp32 value that carries ~1e-7 of noise).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import multimodal_segmentation_project_amd as mi  # noqa: F401
+from multimodal_segmentation_project_amd import _lib
+from multimodal_segmentation_project_amd import metrics as M
+from multimodal_segmentation_project_amd._lib import call, ptr
+from multimodal_segmentation_project_amd.unet import UNet3D
+
+DEV = "cuda:0"
+HALF_ULP = 2.0 ** -9          # bf16: 8 significant bits -> rounding error <= 2^-9 relative
+EPS = 1e-5
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def dyadic(rng, shape, lo=-16, hi=16, den=8.0):
+    return (rng.integers(lo, hi + 1, shape) / den).astype(np.float32)
+
+
+def cl_bf16(a):
+    """NCDHW float array -> channels-last bf16 device tensor [N][D][H][W][C] (values must be bf16-exact)."""
+    t = torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 4, 1))).to(DEV).bfloat16()
+    assert torch.equal(t.float().cpu(), torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 3, 4, 1))))
+    return t
+
+
+def ncdhw(t):
+    return t.float().cpu().numpy().transpose(0, 4, 1, 2, 3)
+
+
+def close_bf16(got, ref, abs_tol, what):
+    """stored bf16 value vs the exact value: half an ULP of the exact value + the fp32 noise of the expression."""
+    bound = HALF_ULP * 1.02 * np.abs(ref) + abs_tol
+    bad = np.abs(got.astype(np.float64) - ref.astype(np.float64)) > bound
+    assert not bad.any(), (what, int(bad.sum()), float(np.abs(got - ref)[bad].max()))
+
+
+BN_CASES = [
+    # N, C, D, H, W, dropout p (0 = none)         which kernels
+    (2, 16, 8, 16, 16, 0.0),      # VEC=8, small tensor: <= 128 partial rows finished in the consumers' prologues
+    (2, 32, 6, 8, 8, 0.5),        # Dropout3d masks that differ per sample (scale 0 or 2)
+    (1, 256, 6, 6, 6, 0.0),       # level-4 shape: 32 channel groups per row
+    (2, 16, 32, 48, 48, 0.0),     # M*C > 2^21: the finalize-launch route (bn_stats_finalize / bn_bwd_finalize)
+    (2, 64, 24, 24, 24, 0.5),     # level-2 shape of the 96^3 step, with masks
+]
+
+
+@pytest.mark.parametrize("case", BN_CASES)
+def test_bn_relu_drop_bf16_vec8_per_op_vs_c_oracle(orc, case):
+    """mi3d_bn_relu_drop_forward / _backward in bf16 with C % 8 == 0 = bn_stats / bn_apply / bn_bwd_reduce(_slab) /
+    bn_bwd_apply <bf16, 8>, the instantiations that are 27 % of the 96^3 step: stat, running buffers, z, dy, dgamma, dbeta."""
+    n, c, d, h, w, p = case
+    rng = np.random.default_rng(c * 1000 + d)
+    y = dyadic(rng, (n, c, d, h, w))
+    # a per-channel offset so that means are not ~0 and (y - mean) cancels for real
+    y += (rng.integers(-8, 9, (1, c, 1, 1, 1)) / 4.0).astype(np.float32)
+    dz = dyadic(rng, (n, c, d, h, w), -8, 8, 4.0)
+    gamma = (rng.random(c) + 0.5).astype(np.float32)
+    beta = (rng.standard_normal(c) * 0.3).astype(np.float32)
+    rm0, rv0 = (rng.standard_normal(c) * 0.1).astype(np.float32), (rng.random(c) + 0.5).astype(np.float32)
+    scale = None
+    if p > 0:
+        scale = (rng.random((n, c)) >= p).astype(np.float32) / (1.0 - p)
+        assert set(np.unique(scale).tolist()) == {0.0, 2.0}
+        assert (scale[0] != scale[1]).any()
+    m, v = n * d * h * w, d * h * w
+    ycl, dzcl = cl_bf16(y), cl_bf16(dz)
+    g_d, b_d = torch.from_numpy(gamma).to(DEV), torch.from_numpy(beta).to(DEV)
+    rm, rv = torch.from_numpy(rm0).to(DEV), torch.from_numpy(rv0).to(DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    drop = torch.from_numpy(scale).to(DEV) if scale is not None else None
+    ws = torch.zeros(_lib.lib().mi3d_bn_workspace_bytes(c), dtype=torch.uint8, device=DEV)
+    stat = torch.empty(4 * c, device=DEV)
+    z = torch.empty_like(ycl)
+    call("mi3d_bn_relu_drop_forward", 1, ptr(ycl), c, c, m, v, ptr(g_d), ptr(b_d), ptr(rm), ptr(rv), ptr(nbt), 0.1, EPS, 1,
+         ptr(drop), ptr(z), c, ptr(stat), ptr(ws), None)
+    yhat, sm, si, rm_ref, rv_ref = orc.bn_train_fwd(y, gamma, beta, rm0, rv0, 0.1, EPS)
+    st = stat.cpu().numpy().reshape(4, c)
+    np.testing.assert_allclose(st[0], sm, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(st[1], si, rtol=2e-6)
+    np.testing.assert_allclose(st[2], gamma * si, rtol=2e-6)
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv_ref, rtol=2e-6)
+    assert int(nbt) == 1
+    z_ref = orc.relu_drop_fwd(yhat, scale)
+    close_bf16(ncdhw(z), z_ref, 2e-6, "z")
+    # ---- backward, with the statistics the forward saved
+    dy = torch.empty_like(ycl)
+    dg, db = torch.full((c,), 7.0, device=DEV), torch.full((c,), -3.0, device=DEV)
+    call("mi3d_bn_relu_drop_backward", 1, ptr(dzcl), c, ptr(ycl), c, c, m, v, ptr(stat), ptr(drop), ptr(dy), c, ptr(dg),
+         ptr(db), 0, ptr(ws), None)
+    # the oracle's chain: dropout/ReLU mask on the BN OUTPUT, then BatchNorm backward with the saved mean / invstd
+    yhat_k = (y.astype(np.float64) * st[2].reshape(1, c, 1, 1, 1) + st[3].reshape(1, c, 1, 1, 1)).astype(np.float32)
+    dyh = orc.relu_drop_bwd(yhat_k, dz, scale)
+    dy_ref, dg_ref, db_ref = orc.bn_train_bwd(y, dyh, gamma, st[0], st[1])
+    # dbeta = sum of dyadic numbers: exact in fp32 in any order
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref, rtol=0, atol=1e-4 * max(1.0, float(np.abs(db_ref).max()) * 1e-3))
+    scale_g = np.sqrt(m) * 4.0
+    np.testing.assert_allclose(dg.cpu().numpy(), dg_ref, rtol=2e-5, atol=2e-6 * scale_g)
+    close_bf16(ncdhw(dy), dy_ref, 2e-5, "dy")
+    # accumulate = 1 adds to the existing parameter gradients
+    call("mi3d_bn_relu_drop_backward", 1, ptr(dzcl), c, ptr(ycl), c, c, m, v, ptr(stat), ptr(drop), ptr(dy), c, ptr(dg),
+         ptr(db), 1, ptr(ws), None)
+    np.testing.assert_allclose(db.cpu().numpy(), 2 * db_ref, rtol=0, atol=2e-4 * max(1.0, float(np.abs(db_ref).max()) * 1e-3))
+    np.testing.assert_allclose(dg.cpu().numpy(), 2 * dg_ref, rtol=2e-5, atol=4e-6 * scale_g)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 8, 16, 32, 0.0), (2, 32, 12, 8, 16, 0.5), (1, 128, 12, 12, 12, 0.0)])
+def test_bn_apply_pool_fused_bf16_per_op_vs_c_oracle(orc, case):
+    """bn_apply_pool_kernel<bf16, 8> (the second half of every encoder block of the step): z as above AND pooled =
+    MaxPool3d(2,2) of the STORED z (exact: a maximum of bf16 values), against the oracle's pool of the kernel's own z and
+    against the two-launch route."""
+    n, c, d, h, w, p = case
+    rng = np.random.default_rng(c + d)
+    y = dyadic(rng, (n, c, d, h, w))
+    gamma = (rng.random(c) + 0.5).astype(np.float32) * np.where(rng.random(c) < 0.3, -1.0, 1.0).astype(np.float32)   # negative slopes too
+    beta = (rng.standard_normal(c) * 0.3).astype(np.float32)
+    scale = (rng.random((n, c)) >= p).astype(np.float32) / (1.0 - p) if p > 0 else None
+    m, v = n * d * h * w, d * h * w
+    ycl = cl_bf16(y)
+    g_d, b_d = torch.from_numpy(gamma).to(DEV), torch.from_numpy(beta).to(DEV)
+    drop = torch.from_numpy(scale).to(DEV) if scale is not None else None
+    ws = torch.zeros(_lib.lib().mi3d_bn_workspace_bytes(c), dtype=torch.uint8, device=DEV)
+    outs = []
+    for fused in (True, False):
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        stat = torch.empty(4 * c, device=DEV)
+        z = torch.empty_like(ycl)
+        pooled = torch.empty((n, d // 2, h // 2, w // 2, c), device=DEV, dtype=torch.bfloat16)
+        if fused:
+            call("mi3d_bn_relu_drop_pool_forward", 1, ptr(ycl), c, c, n, d, h, w, ptr(g_d), ptr(b_d), ptr(rm), ptr(rv), ptr(nbt),
+                 0.1, EPS, ptr(drop), ptr(z), c, ptr(pooled), c, ptr(stat), ptr(ws), None)
+        else:
+            call("mi3d_bn_relu_drop_forward", 1, ptr(ycl), c, c, m, v, ptr(g_d), ptr(b_d), ptr(rm), ptr(rv), ptr(nbt), 0.1, EPS, 1,
+                 ptr(drop), ptr(z), c, ptr(stat), ptr(ws), None)
+            call("mi3d_maxpool2_forward", 1, ptr(z), c, c, n, d, h, w, ptr(pooled), c, None)
+        outs.append((z.clone(), pooled.clone(), stat.clone(), rm.clone(), rv.clone(), int(nbt)))
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)                                   # fused == two launches, bit for bit
+    assert outs[0][5] == outs[1][5] == 1
+    z, pooled = outs[0][0], outs[0][1]
+    yhat, _, _, _, _ = orc.bn_train_fwd(y, gamma, beta, np.zeros(c, np.float32), np.ones(c, np.float32), 0.1, EPS)
+    close_bf16(ncdhw(z), orc.relu_drop_fwd(yhat, scale), 2e-6, "z")
+    np.testing.assert_array_equal(ncdhw(pooled), orc.maxpool2_fwd(ncdhw(z)))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16), (1, 5, 7, 9), (2, 4, 6, 50)])
+def test_conv1_head_bf16_per_op_exact(shape):
+    """The final 1x1x1 conv (models/unet.py:62,87) through mi3d_conv1_forward / mi3d_conv1_backward in bf16 = conv1_fwd_kernel
+    and conv1_bwd_mfma_kernel (+ its slab sum) of the training step.  Dyadic inputs: logits, dW and db are exact in fp32
+    (compared with atol 1e-6), dz is the exactly computed sum rounded to bf16 once (bitwise)."""
+    n, d, h, w = shape
+    cin, cout = 16, 4
+    v = d * h * w
+    rng = np.random.default_rng(v)
+    z = dyadic(rng, (n, cin, d, h, w), -8, 8, 8.0)
+    wgt = dyadic(rng, (cout, cin), -4, 4, 4.0)
+    bias = dyadic(rng, (cout,), -4, 4, 4.0)
+    dl = dyadic(rng, (n, cout, d, h, w), -8, 8, 8.0)
+    zcl = cl_bf16(z)
+    w_d, b_d = torch.from_numpy(wgt.reshape(cout, cin, 1, 1, 1)).to(DEV), torch.from_numpy(bias).to(DEV)
+    logits = torch.empty((n, cout, d, h, w), device=DEV)
+    call("mi3d_conv1_forward", 1, ptr(zcl), cin, cin, ptr(w_d), ptr(b_d), ptr(logits), cout, n, v, None)
+    ref = np.einsum("oc,ncdhw->nodhw", wgt.astype(np.float64), z.astype(np.float64)) + bias.reshape(1, cout, 1, 1, 1)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref, rtol=0, atol=1e-6)
+    dl_d = torch.from_numpy(dl).to(DEV)
+    dz = torch.empty_like(zcl)
+    dW, db = torch.empty((cout, cin, 1, 1, 1), device=DEV), torch.empty(cout, device=DEV)
+    wsb = _lib.lib().mi3d_conv1_workspace_bytes(cin, cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    call("mi3d_conv1_backward", 1, ptr(zcl), cin, cin, ptr(w_d), ptr(dl_d), cout, ptr(dz), cin, ptr(dW), ptr(db), 0, n, v, ptr(ws),
+         wsb, None)
+    dz_ref = np.einsum("oc,nodhw->ncdhw", wgt.astype(np.float64), dl.astype(np.float64))
+    dz_ref_bf16 = torch.from_numpy(dz_ref.astype(np.float32)).bfloat16().float().numpy()      # one RNE rounding of the exact value
+    np.testing.assert_array_equal(ncdhw(dz), dz_ref_bf16)
+    dW_ref = np.einsum("nodhw,ncdhw->oc", dl.astype(np.float64), z.astype(np.float64))
+    np.testing.assert_allclose(dW.cpu().numpy().reshape(cout, cin), dW_ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(db.cpu().numpy(), dl.astype(np.float64).sum(axis=(0, 2, 3, 4)), rtol=0, atol=1e-6)
+    # accumulate
+    call("mi3d_conv1_backward", 1, ptr(zcl), cin, cin, ptr(w_d), ptr(dl_d), cout, ptr(dz), cin, ptr(dW), ptr(db), 1, n, v, ptr(ws),
+         wsb, None)
+    np.testing.assert_allclose(dW.cpu().numpy().reshape(cout, cin), 2 * dW_ref, rtol=0, atol=2e-6)
+
+
+def _synth(n, s, seed, blocky=True):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 1, s, s, s, generator=g)
+    y = torch.randint(0, 4, (n, 1, s, s, s), generator=g)
+    if blocky:
+        zz, yy, xx = torch.meshgrid(torch.arange(s), torch.arange(s), torch.arange(s), indexing="ij")
+        lab = ((zz // (s // 4)) + (yy // (s // 4)) + (xx // (s // 4))) % 4
+        y = lab[None, None].expand(n, 1, s, s, s).contiguous().long()
+        x = y.float() / 3.0 + 0.1 * x
+    return x, y
+
+
+def test_round2_routes_are_invisible_at_the_headline_shape(monkeypatch):
+    """96^3, N=2, bf16 -- the kernel routes added in round 2, each switched off in turn against the default build, per TENSOR:
+      MI3D_NO_SMALL_BN        BatchNorm statistics finished by a finalize launch instead of the consumer's prologue: the SAME
+                              partial rows summed in double in another order -> statistics equal to ~1e-7, everything
+                              downstream within bf16 re-rounding noise
+      MI3D_NO_DEFER_TAIL      split-K input gradients finished by their own pass instead of inside the next BatchNorm-backward
+                              reduction: the same fp32 partials in the same order -> bitwise
+      MI3D_NO_FUSED_BWD_BIG   level-1 weight gradient + input gradient in two launches instead of one: same bodies, another
+      MI3D_NO_FUSED_BWD_P     slab partition (summation order) for the weight gradients only; same for the persistent pair."""
+    torch.manual_seed(0)
+    m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+    m.compute_dtype = torch.bfloat16
+    x, y = _synth(2, 96, 1234)
+    x, y = x.to(DEV), y.to(DEV)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        o = m(x)
+        l = M.combined_loss(o, y)
+        l.backward()
+        return l.item(), o.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    def noise_only(k):       # conv bias in front of train-mode BN: analytically zero, pure summation noise
+        return k.endswith("double_conv.0.bias") or k.endswith("double_conv.4.bias")
+
+    l0, o0, g0 = run()
+    monkeypatch.setenv("MI3D_NO_DEFER_TAIL", "1")
+    l1, o1, g1 = run()
+    assert l1 == l0 and torch.equal(o1, o0)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    monkeypatch.delenv("MI3D_NO_DEFER_TAIL")
+    for sw in ("MI3D_NO_FUSED_BWD_BIG", "MI3D_NO_FUSED_BWD_P"):
+        monkeypatch.setenv(sw, "1")
+        l2, o2, g2 = run()
+        monkeypatch.delenv(sw)
+        assert l2 == l0 and torch.equal(o2, o0)
+        for k in g0:
+            if float(g0[k].double().norm()) < 1e-7 or noise_only(k):
+                continue
+            assert relerr(g2[k].cpu(), g0[k].cpu()) < 1e-5, (sw, k, relerr(g2[k].cpu(), g0[k].cpu()))
+    monkeypatch.setenv("MI3D_NO_SMALL_BN", "1")
+    l3, o3, g3 = run()
+    monkeypatch.delenv("MI3D_NO_SMALL_BN")
+    assert abs(l3 - l0) < 1e-5 * abs(l0)
+    assert relerr(o3.cpu(), o0.cpu()) < 2e-3
+    worst = 0.0
+    for k in g0:
+        n0 = float(g0[k].double().norm())
+        if n0 < 1e-7 or noise_only(k):
+            continue
+        e = relerr(g3[k].cpu(), g0[k].cpu())
+        worst = max(worst, e)
+        # statistics differ in the last fp32 bit -> a few bf16 activations re-round; full-resolution tensors average it out,
+        # deep-level tensors (cancellation sums of few elements) see it at the percent level
+        assert e < (2e-3 if ("encoder.0" in k or "decoder.3" in k or "final" in k) else 5e-2), (k, e)
+    print("MI3D_NO_SMALL_BN at 96^3: worst per-tensor relerr", worst)

@@ -40,7 +40,11 @@ def _import_reference():
             pass
 
     mt = sys.modules["monai.transforms"]
-    mt.__getattr__ = lambda name: _AnyTransform   # PEP 562: any transform name resolves to a dummy
+    def _any(name):                               # PEP 562: any transform name resolves to a dummy
+        if name.startswith("__"):                 # ... but module dunders (__file__, __path__: inspect.getmodule) do not exist
+            raise AttributeError(name)
+        return _AnyTransform
+    mt.__getattr__ = _any
     import models.unet as ref_unet
     import models.unet_dann as ref_unet_dann
     import utils.metrics as ref_metrics
@@ -799,11 +803,124 @@ def gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, out):
     np.savez_compressed(os.path.join(out, "loops.npz"), **d)
 
 
+# ---------------------------------------------------------------------------------------------- data-parallel (A15)
+def _dp2_data(kind):
+    """Per-rank micro-batches of the dp2 fixture, regenerated from seeds by the tests (nothing but seeds is stored)."""
+    if kind == "plain":          # 2 micro-batches per rank, N = 2, 32^3: rank r sees seeds 1000 + 10 r + i
+        return [[synth(2, 32, 1000 + 10 * r + i, blocky=(i % 2 == 0)) for i in range(2)] for r in range(2)]
+    # "loader": ONE dataset of 6 batches of N = 2 (seeds 1100 + b); accelerate's BatchSamplerShard deals batch b to rank b % 2
+    return [synth(2, 32, 1100 + b, blocky=(b % 2 == 1)) for b in range(6)]
+
+
+def _dp2_worker(rank, out_path):
+    """One of the two CPU ranks (gloo): the reference's train_one_epoch under accelerate exactly as train_unet.py:309-312,
+    384-386 sets it up -- Accelerator(...) -> prepare(model, optimizer[, loader]) = DDP wrap -> accumulate / backward /
+    gather.  Captures what a rank observes: the returned means, its (all-reduced) gradients, its BatchNorm buffers."""
+    import tempfile
+    from accelerate import Accelerator
+    try:
+        import datasets  # noqa: F401  (accelerate.prepare(DataLoader) imports it; it must probe for nibabel BEFORE the stand-ins exist)
+    except ImportError:
+        pass
+    ref_unet, _, _, ref_train_unet, _ = _import_reference()
+    torch.set_num_threads(4)
+    d = {}
+    tmp = tempfile.mkdtemp()
+    args = _Args()
+    args.epochs, args.experiment_dir, args.experiment_name = 1, tmp, "x"
+    os.makedirs(os.path.join(tmp, "x", "logs"), exist_ok=True)
+    loss_fn = ref_train_unet.get_loss_fn("combined")
+
+    def fresh(accum):
+        acc = Accelerator(gradient_accumulation_steps=accum, cpu=True)
+        assert acc.num_processes == 2 and acc.process_index == rank, (acc.num_processes, acc.process_index)
+        torch.manual_seed(0)
+        m = ref_unet.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        return acc, m, opt
+
+    # ---- plain/: accumulation 1, each rank iterates its own list of micro-batches (the reference's loop with a sharded
+    # sampler); stopped after ONE step (gradients = mean over ranks at the initial parameters) and after TWO steps
+    data = _dp2_data("plain")[rank]
+    for tag, nb in (("plain1/", 1), ("plain2/", 2)):
+        acc, m, opt = fresh(1)
+        m, opt = acc.prepare(m, opt)
+        res = ref_train_unet.train_one_epoch(m, data[:nb], opt, acc, 0, args, loss_fn)
+        raw = acc.unwrap_model(m)
+        d[tag + "result"] = np.array([float(v) for v in res])
+        _summ(d, tag, raw)
+        _, dig = param_digest(raw.state_dict())
+        d[tag + "param_digest_after"] = dig
+        acc.free_memory()
+    # ---- loader/: accumulation 2 over a PREPARED DataLoader of 3 batches per rank (3 % 2 != 0): accelerate forces
+    # sync + optimizer.step on the last batch of the epoch (GradientState.end_of_dataloader), so the steps land on batches
+    # 2 and 3; with the reference's zero_grad-inside-accumulate (Q2) the applied gradients are g2/2 and then g3/2
+    batches = _dp2_data("loader")
+    xs = torch.cat([b[0] for b in batches]); ys = torch.cat([b[1] for b in batches])
+    dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(xs, ys), batch_size=2, shuffle=False)
+    acc, m, opt = fresh(2)
+    m, opt, dl = acc.prepare(m, opt, dl)
+    seen = []
+    steps = []
+    raw = acc.unwrap_model(m)
+    real_step = opt.optimizer.step
+
+    def counting_step(*a, **k):
+        steps.append(len(seen))
+        return real_step(*a, **k)
+    opt.optimizer.step = counting_step
+
+    class _Spy:                      # records which samples this rank saw, in order (first voxel of each volume)
+        def __init__(self, it): self.it = it
+        def __len__(self): return len(self.it)
+        def __iter__(self):
+            for xb, yb in self.it:
+                seen.append(float(xb.double().sum()))
+                yield xb, yb
+    res = ref_train_unet.train_one_epoch(m, _Spy(dl), opt, acc, 0, args, loss_fn)
+    d["loader/result"] = np.array([float(v) for v in res])
+    d["loader/seen_sum"] = np.array(seen)
+    d["loader/step_after_batch"] = np.array(steps)
+    _summ(d, "loader/", raw)
+    _, dig = param_digest(raw.state_dict())
+    d["loader/param_digest_after"] = dig
+    np.savez_compressed(out_path, **d)
+
+
+def gen_dp2(out):
+    """A15 / SURVEY 2.2 C1-C4 pinned to the reference: TWO CPU processes (gloo) run train_unet.train_one_epoch under
+    accelerate's DDP wrap on per-rank shards.  dp2.npz holds, per rank r, `r{r}/...`: returned means (already gathered and
+    averaged over ranks by the reference), gradient norms / slices (identical on both ranks: DDP averages), BatchNorm
+    buffers (rank-local statistics; DDP broadcasts rank 0's at every forward), parameter digests after the steps."""
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    port = 29611
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ACCELERATE_USE_CPU="1", OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--dp2-worker", str(r),
+                                       "--out", os.path.join(tmp, f"r{r}.npz")], env=env))
+    for pr in procs:
+        if pr.wait(timeout=1800) != 0:
+            raise RuntimeError("dp2 worker failed")
+    d = {}
+    for r in range(2):
+        for k, v in np.load(os.path.join(tmp, f"r{r}.npz"), allow_pickle=False).items():
+            d[f"r{r}/{k}"] = v
+    np.savez_compressed(os.path.join(out, "dp2.npz"), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     ap.add_argument("--only", default="", help="comma-separated fixture names (default: all)")
+    ap.add_argument("--dp2-worker", type=int, default=-1, help="internal: rank of a gen_dp2 worker process")
     a = ap.parse_args()
+    if a.dp2_worker >= 0:
+        _dp2_worker(a.dp2_worker, a.out)
+        return
     only = set(filter(None, a.only.split(",")))
     want = lambda name: not only or name in only
     os.makedirs(a.out, exist_ok=True)
@@ -820,6 +937,7 @@ def main():
     if want("oddsize"): gen_oddsize(ref_unet, ref_metrics, a.out)
     if want("preproc"): gen_preproc(a.out)
     if want("loops"): gen_loops(ref_unet, ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
+    if want("dp2"): gen_dp2(a.out)
     if want("config2_96"): gen_config2(ref_unet, ref_metrics, a.out)
     if want("config4_dann96"): gen_config4(ref_unet_dann, ref_train_unet, ref_train_dann, a.out)
     if want("config5_128"): gen_config5(ref_unet, ref_metrics, a.out)
