@@ -97,12 +97,13 @@ def _kernel_traffic(kernel_substr, ms):
         return None
 
 
-def roofline_dominant(size, batch, dtype_code, iters=10):
+def roofline_dominant(size, batch, dtype_code, iters=10, ts=None):
     """Dominant kernel = the launch with the largest time per step (profiles/rNN_step_timeline.txt): the fused backward of
     decoder.3.conv0 (32 -> 16 channels at full resolution), conv3_bwd_fused_persist_kernel<2,1> = input gradient + weight
     gradient of the layer in one launch.  Timed live with HIP events recorded tightly around THAT kernel on the stream it is
-    launched on (mi3d_time_next_conv3_bwd_kernel; the per-operator call also launches a weight pack and a slab sum, which
-    stay outside the events).  Algorithmic bytes per launch = read dy once + read x once + write dx once (+ dW):
+    launched on (mi3d_time_next_conv3_bwd_kernel), inside real training steps when the TrainStep `ts` is given (the kernel
+    with the step's own data and layout: the skip/up halves of the concat buffer are two planes there), else inside the
+    per-operator call.  Algorithmic bytes per launch = read dy once + read x once + write dx once (+ dW):
     M * (Cout + Cin + Cin) * 2 B -- both products of the layer share one read of dy in the ideal kernel."""
     import ctypes as C
     from multimodal_segmentation_project_amd import _lib
@@ -112,30 +113,40 @@ def roofline_dominant(size, batch, dtype_code, iters=10):
     esz = 2 if dtype_code == 1 else 4
     T = torch.bfloat16 if dtype_code == 1 else torch.float32
     n, d = batch, size
-    x = torch.randn((n, d, d, d, cin), device=dev).to(T)
-    dy = torch.randn((n, d, d, d, cout), device=dev).to(T)
-    w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
-    dx = torch.empty_like(x)
-    dW, db = torch.empty_like(w), torch.empty(cout, device=dev)
-    wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, d, d)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    s = stream_ptr()
-
-    def once():
-        call("mi3d_conv3_backward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(dy), cout, cout, ptr(dx), cin, ptr(dW),
-             ptr(db), 0, n, d, d, d, ptr(ws), wsb, s)
-    for _ in range(2):
-        once()
     vox = n * d ** 3
     algo_bytes = vox * (cout + cin + cin) * esz + cout * cin * 27 * 4
     kernel = "conv3_bwd_fused_persist_kernel<2, 1>"
+    in_step = ts is not None and dtype_code == 1 and d % 16 == 0 and d >= 32
+    if not in_step:
+        x = torch.randn((n, d, d, d, cin), device=dev).to(T)
+        dy = torch.randn((n, d, d, d, cout), device=dev).to(T)
+        w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
+        dx = torch.empty_like(x)
+        dW, db = torch.empty_like(w), torch.empty(cout, device=dev)
+        wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, d, d)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        s = stream_ptr()
+
+        def once():
+            call("mi3d_conv3_backward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(dy), cout, cout, ptr(dx), cin, ptr(dW),
+                 ptr(db), 0, n, d, d, d, ptr(ws), wsb, s)
+        skip = 0
+    else:
+        was = ts.use_graph
+        ts.use_graph = False                   # eager launches: the hook needs the launch to happen in this call
+
+        def once():
+            ts.step_static()
+        skip = 1                               # backward launch order: decoder.3.conv1 (<1,1>), then decoder.3.conv0 (<2,1>)
+    for _ in range(2):
+        once()
     if dtype_code == 1:
         e0, e1 = C.c_void_p(), C.c_void_p()
         call("mi3d_timing_event_create", C.byref(e0))
         call("mi3d_timing_event_create", C.byref(e1))
         tot = 0.0
         for _ in range(iters):
-            call("mi3d_time_next_conv3_bwd_kernel", e0, e1)
+            call("mi3d_time_next_conv3_bwd_kernel", e0, e1, skip)
             once()
             t = C.c_float()
             call("mi3d_event_elapsed_ms", e0, e1, C.byref(t))
@@ -152,8 +163,11 @@ def roofline_dominant(size, batch, dtype_code, iters=10):
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / iters
+    if in_step:
+        ts.use_graph = was
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": kernel + " = conv3 bwd 32->16 (decoder.3.conv0: input gradient + weight gradient)",
+            "measured": "inside training steps" if in_step else "per-operator call",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": _kernel_traffic(kernel, ms), "ms_per_launch": ms, "algorithmic_bytes_per_launch": algo_bytes,
             "flops_per_launch": 2 * 2 * 27 * cin * cout * vox}
@@ -176,6 +190,8 @@ def main():
     ap.add_argument("--graph-segments", action="store_true", help="world > 1 / --force-comm: replay one hipGraph per comm-free run of kernels")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: create a 1-rank RCCL group and drive the DP bucket path (side stream, all-reduces, segmented graphs)")
+    ap.add_argument("--serial-forwards", action="store_true",
+                    help="distill / dann: run the two independent forwards one after the other instead of on two streams")
     ap.add_argument("--workload", default="train", choices=["train", "distill", "dann", "eval"],
                     help="train = the headline metric (BASELINE config 2/3); distill = config 5 step (student + frozen teacher); "
                          "dann = config 4 step (N source + N target volumes per GPU); eval = inference forward + loss + metrics")
@@ -229,7 +245,7 @@ def main():
             torch.manual_seed(1)
             teacher = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).eval()
         ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt, kd_teacher=teacher,
-                       use_graph=use_graph, two_stream=a.two_stream)
+                       use_graph=use_graph, two_stream=a.two_stream, overlap_teacher=not a.serial_forwards)
         ts.load_batch(x.to(dev), y.to(dev))
     if a.workload == "eval":
         xd, yd = x.to(dev), y.to(dev)
@@ -273,7 +289,8 @@ def main():
             "step_algorithmic_gb": algo_gb_step,
         }
         if not a.no_roofline:
-            res["roofline"] = roofline_dominant(a.size, a.batch, 1 if a.dtype == "bf16" else 0)
+            res["roofline"] = roofline_dominant(a.size, a.batch, 1 if a.dtype == "bf16" else 0,
+                                                ts=ts if (a.workload == "train" and a.dropout == 0.0 and not ts.do_comm) else None)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.size, a.batch)
         print(json.dumps(res))

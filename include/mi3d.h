@@ -97,11 +97,19 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
 int mi3d_event_create(void** event_out);
 int mi3d_event_destroy(void* event);
 /* Measurement hooks (bench.py `roofline`: HIP events around ONE kernel on the stream it is launched on).
- * mi3d_time_next_conv3_bwd_kernel: the next fused conv backward launch (mi3d_conv3_backward / mi3d_unet_backward on the calling
- * thread) records start/stop -- timing events from mi3d_timing_event_create -- tightly around its kernel; one-shot.
+ * mi3d_time_next_conv3_bwd_kernel: the (skip+1)-th full-resolution fused conv backward launch from now (mi3d_conv3_backward /
+ * mi3d_unet_backward on the calling thread; in the backward of a UNet3D step launch 0 is decoder.L-1.conv1, launch 1
+ * decoder.L-1.conv0) records start/stop -- timing events from mi3d_timing_event_create -- tightly around its kernel; one-shot.
  * mi3d_event_elapsed_ms synchronises on `stop`. */
+/* mi3d_debug_occupy_cus: a stand-in for a resident collective kernel (RCCL all-reduce) on a 1-GPU box: `workgroups` x 512
+ * threads x 128 VGPRs hold their CU slots for `microseconds` on `stream` and read through buf[0..n) meanwhile
+ * (bench.py --emulate-comm: what a collective beside the encoder backward costs the persistent grids). */
+int mi3d_debug_occupy_cus(int workgroups, int microseconds, float* buf, int64_t n, void* stream);
+/* mi3d_set_cu_budget: CUs (0..128) the persistent conv grids launched from the calling thread leave free for a collective
+ * kernel that is resident beside them (TrainStep sets it for the backward segments that overlap a gradient exchange). */
+int mi3d_set_cu_budget(int cus);
 int mi3d_timing_event_create(void** event_out);
-int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event);
+int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event, int skip);
 int mi3d_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out);
 /* params-table index ranges whose gradients segment `seg` produces: ranges = {first0, last0, first1, last1}
  * (half-open; the second range is the segment's upconv for decoder segments, otherwise {-1,-1}) */

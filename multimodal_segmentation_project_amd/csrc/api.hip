@@ -85,6 +85,9 @@ int mi3d_adamw_apply(float* p, const float* g, float* m, float* v, int64_t n, fl
     MI3D_CHECK_ARG(step_dev && (n == 0 || (p && g && m && v)) && n >= 0, "mi3d_adamw_apply: bad arguments");
     return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_dev, (hipStream_t)stream, increment);
 }
+int mi3d_debug_occupy_cus(int workgroups, int microseconds, float* buf, int64_t n, void* stream) {
+    return occupy_cus(workgroups, microseconds, buf, n, (hipStream_t)stream);
+}
 int mi3d_dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, void* stream) {
     MI3D_CHECK_ARG(out && state_dev && n >= 0 && p >= 0.f && p <= 1.f, "mi3d_dropout_scales: bad arguments");
     return dropout_scales(out, n, p, state_dev, (hipStream_t)stream);

@@ -865,6 +865,12 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_dma_kernel(const bf
 }
 
 constexpr int PERSIST_WGS = 512;
+// CU budget (mi3d_set_cu_budget): CUs the caller wants left free of persistent workgroups because a collective kernel is
+// resident on them (data-parallel step: the gradient all-reduce runs beside the encoder backward).  A persistent grid sized
+// for all 256 CUs would otherwise run a second, partial round on the CUs it has to share.
+static thread_local int g_cu_budget = 0;
+extern "C" int mi3d_set_cu_budget(int cus) { g_cu_budget = cus < 0 ? 0 : (cus > 128 ? 128 : cus); return 0; }
+inline int persist_cus() { return 256 - g_cu_budget; }
 inline bool persist_ok(int Cin, int Cout, Geo g) {
     // 16 -> 32 (two co blocks, 256 VGPRs): only worth it with >= 2 tiles per workgroup; the one-tile-per-workgroup
     // generic kernel is faster below that (level 1 of the 96^3 net)
@@ -875,7 +881,7 @@ inline bool persist_ok(int Cin, int Cout, Geo g) {
 }
 inline int persist_grid(int Cin, int Cout, Geo g) {
     int64_t nt = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
-    int want = PERSIST_WGS;      // 2 resident workgroups per CU
+    int want = 2 * persist_cus();      // 2 resident workgroups per CU
     return (int)(nt < want ? nt : want);
 }
 
@@ -1584,7 +1590,7 @@ inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     c.nt = 27;
     c.tg = 1;
     // persistent: one round of workgroups, 2 per CU
-    int64_t want = 512 / (int64_t)groups;
+    int64_t want = 2 * persist_cus() / (int64_t)groups;
     if (want < 1) want = 1;
     int64_t rounds = cdiv(ntiles, want);               // tiles per workgroup; then the fewest slabs that keep it
     c.nsb = (int)cdiv(ntiles, rounds);
@@ -1653,9 +1659,11 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
 }
 
 static thread_local hipEvent_t g_time_ev[2] = {nullptr, nullptr};
-extern "C" int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event) {
+static thread_local int g_time_skip = 0;
+extern "C" int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event, int skip) {
     g_time_ev[0] = (hipEvent_t)start_event;
     g_time_ev[1] = (hipEvent_t)stop_event;
+    g_time_skip = skip < 0 ? 0 : skip;
     return 0;
 }
 
@@ -1670,7 +1678,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     MI3D_CHECK_ARG(conv3_mfma_bwd_fused_persist_ok(Cin, Cout, xcs, dycs, g) && dx, "conv3_mfma_bwd_fused_persist: unsupported layer");
     int groups = (Cout / 16) * (Cin / 16);
     int64_t ntw = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
-    const int wcap = 256, pcap = 256;          // one workgroup of each kind per CU (512 + 512 = no co-residency: measured equal to unfused)
+    const int wcap = persist_cus(), pcap = persist_cus();   // one workgroup of each kind per CU (512 + 512 = no co-residency: measured equal to unfused)
     int64_t want = wcap / groups; if (want < 1) want = 1;
     int64_t rounds = cdiv(ntw, want);
     int nsb = (int)cdiv(ntw, rounds);
@@ -1690,8 +1698,8 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     // dgrad conv Cout -> Cin: persistent shapes (16,16): <1,1>, (32->16): <1,2>, (16->32): <2,1>
     size_t ldsw = (size_t)(WNV + WNH) * 32;
     // measurement hook (mi3d_time_next_conv3_bwd_kernel): one-shot HIP events tightly around this kernel
-    hipEvent_t tev0 = g_time_ev[0], tev1 = g_time_ev[1];
-    g_time_ev[0] = g_time_ev[1] = nullptr;
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    if (g_time_ev[0] && g_time_skip-- == 0) { tev0 = g_time_ev[0]; tev1 = g_time_ev[1]; g_time_ev[0] = g_time_ev[1] = nullptr; }
 #define FP(COB_, NCH_)                                                                                                        \
     do {                                                                                                                      \
         size_t ldsp = (size_t)(6 * 10 * 18 * 16 + NCH_ * 14 * COB_ * 512) * 2 + 4 * COB_ * 16 * 2 * 4;                        \

@@ -9,6 +9,8 @@ connected xGMI node instead of translated from DDP's bucket machinery:
     (four readiness-ordered buckets are available as fine_buckets=True; fewer collective calls measured faster);
   * BatchNorm statistics stay per-rank (DDP + BatchNorm3d semantics, NOT SyncBN).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -78,6 +80,14 @@ class DataParallelComm:
         self.enabled = self.world > 1 or (bool(force) and dist.is_available() and dist.is_initialized())
         self.buckets = bucket_ranges(arena, n_levels, fine=fine_buckets)
         self.backend = dist.get_backend(group) if self.enabled else None
+        # MI3D_EMULATE_COMM="<workgroups>:<microseconds>": every gradient exchange also launches a stand-in kernel that holds
+        # that many CU slots for that long on the communication stream (1-GPU box: a 1-rank all-reduce is a copy and occupies
+        # nothing, so the cost of a RESIDENT collective beside the backward kernels cannot be seen otherwise)
+        self.emulate = None
+        em = os.environ.get("MI3D_EMULATE_COMM", "")
+        if em and self.enabled:
+            w, _, u = em.partition(":")
+            self.emulate = (int(w), int(u or 250))
 
     def broadcast_parameters(self, buffers=()):
         """C1: rank 0's parameters (one flat broadcast) and buffers win."""
@@ -116,3 +126,8 @@ class DataParallelComm:
         r = self.buckets.get(seg)
         if r is not None and self.enabled:
             self.average_(self.arena.g[r[0]:r[1]])
+            if self.emulate is not None and self.arena.g.is_cuda:
+                from ._lib import call, stream_ptr
+                g = self.arena.g[r[0]:r[1]]
+                usec = max(1, int(self.emulate[1] * (r[1] - r[0]) / self.arena.numel))      # duration ~ bytes exchanged
+                call("mi3d_debug_occupy_cus", self.emulate[0], usec, g.data_ptr(), g.numel(), stream_ptr())

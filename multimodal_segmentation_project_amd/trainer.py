@@ -49,6 +49,39 @@ def _loss_cfg(kind, kd_alpha=None, temperature=2.0):
     return M._cfg(*_LOSS_TABLE[kind])
 
 
+def concurrent_stream(device, candidates=6, hold_us=300):
+    """A stream whose kernels really run BESIDE those of the current (compute) stream.  HIP multiplexes streams onto a few
+    hardware queues, and two streams that share a queue execute strictly one after the other (measured with rocprofv3: the
+    default stream and the 8th stream created in a process both sat on queue 4, and a collective kernel on the latter ran
+    between, not beside, the backward kernels -- profiles/r03_dp_streams.txt).  So the communication stream is CHOSEN by a
+    measurement: a stand-in kernel that holds a few workgroups for `hold_us` is launched on the candidate and on the compute
+    stream; if the pair takes about one hold time they overlap.  The first candidate has high priority (its own queue on this
+    runtime).  Falls back to the last candidate, with a warning attribute, when none overlaps."""
+    main = torch.cuda.current_stream(device)
+    buf = torch.zeros(1024, dtype=torch.float32, device=device)
+    best = None
+    for i in range(candidates):
+        c = torch.cuda.Stream(device=device, priority=-1) if i == 0 else torch.cuda.Stream(device=device)
+        times = []
+        for rep in range(2):                       # first pass loads the code object
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            e0.record(main)
+            c.wait_stream(main)
+            call("mi3d_debug_occupy_cus", 4, hold_us, buf.data_ptr(), buf.numel(), c.cuda_stream)
+            call("mi3d_debug_occupy_cus", 4, hold_us, buf.data_ptr(), buf.numel(), main.cuda_stream)
+            main.wait_stream(c)
+            e1.record(main)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e3)
+        c.mi3d_overlap_us = times[-1]
+        c.mi3d_concurrent = times[-1] < 1.5 * hold_us
+        best = c
+        if c.mi3d_concurrent:
+            break
+    return best
+
+
 class ArenaAdamW(torch.optim.Optimizer):
     """`param_groups` surface of the arena optimizer, so that torch.optim.lr_scheduler objects (the reference's
     ReduceLROnPlateau(mode='max', patience=10, factor=0.1, min_lr=1e-6), train_unet.py:381,442) can drive the learning
@@ -103,7 +136,8 @@ class _StepBase:
         self.do_comm = self.world > 1 or (self.force_comm and dist.is_available() and dist.is_initialized())
         self.comm = DataParallelComm(self.arena, n_levels, process_group, force=self.do_comm,
                                      fine_buckets=os.environ.get("MI3D_FINE_BUCKETS", "0") == "1")
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.do_comm else None
+        # the exchange stream must sit on another hardware queue than the compute stream (see concurrent_stream)
+        self.comm_stream = concurrent_stream(self.device) if self.do_comm else None
         self.use_graph = bool(use_graph)
         self._statics = {}
         self._static = None
@@ -265,7 +299,7 @@ class TrainStep(_StepBase):
     def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
                  grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
                  compute_dtype=None, use_graph=False, two_stream=False, reference_zero_grad_quirk=False,
-                 force_comm=False):
+                 force_comm=False, overlap_teacher=True):
         """reference_zero_grad_quirk: train_unet.py:222 / finetune_ct.py:161 call optimizer.zero_grad() INSIDE
         accelerator.accumulate(), where accelerate only really zeroes on the boundary micro-step -> the gradient the
         reference applies is grad(last micro-batch)/accum.  False (default): accumulate all micro-batches
@@ -282,6 +316,11 @@ class TrainStep(_StepBase):
         self.quirk = bool(reference_zero_grad_quirk) and kd_teacher is None
         if kd_teacher is not None:
             self._check_teacher(kd_teacher)
+        # distillation (distill_unet.py:107-112): the frozen teacher's forward does not depend on the student's -- it runs on
+        # its own stream beside the student forward (fork after the batch is in place, join in front of the loss; both
+        # branches are captured into the one step graph).  Separate workspaces and logits: results are bitwise those of the
+        # serial order.  Both forwards are long chains that leave most CUs idle at the deep levels, so they interleave.
+        self.kd_stream = concurrent_stream(self.device) if (kd_teacher is not None and overlap_teacher) else None
         # second compute stream: weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
         self.aux_stream = torch.cuda.Stream(device=self.device) if two_stream else None
         self._events = None
@@ -422,13 +461,22 @@ class TrainStep(_StepBase):
         elif p > 0.0:
             call("mi3d_dropout_scales", ptr(st["drop"]), st["ndrop"], p, ptr(engine._rng_state(model, self.device)), s)
             drop = st["drop"]
+        t_logits = None
+        if self.teacher is not None and self.kd_stream is not None:
+            ks = self.kd_stream
+            ks.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ks):
+                call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"],
+                     ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], ks.cuda_stream)
         call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1,
              ptr(st["logits"]), None, ptr(st["ws"]), st["ws_bytes"], s)
-        t_logits = None
         if self.teacher is not None:
-            # frozen teacher (distill_unet.py:109-111): the BatchNorm-folded inference forward
-            call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"],
-                 ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], s)
+            if self.kd_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.kd_stream)
+            else:
+                # frozen teacher (distill_unet.py:109-111): the BatchNorm-folded inference forward
+                call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"],
+                     ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], s)
             t_logits = st["t_logits"]
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
         # loss + metrics (SURVEY Q1 loop bound D) of the same logits in one pass (replaces 3 argmaxes + 2(D-1) host syncs)
@@ -439,6 +487,7 @@ class TrainStep(_StepBase):
         # point (one fork of the comm stream less) and is in flight under the rest of the backward
         met = st["metrics"]
         met_pending = self.do_comm
+        joined = False
         if run_backward:
             call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
                  ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
@@ -448,21 +497,39 @@ class TrainStep(_StepBase):
             # one C call per run of segments between exchange steps: kernels of adjacent segments share launches (a
             # weight-gradient slab sum rides in the next BatchNorm reduction), which a call boundary would cut
             start = 0
+            # MI3D_COMM_CUS=n: the segments launched while a gradient exchange is in flight size their persistent grids for
+            # 256 - n CUs (the collective kernel holds the others: see mi3d_set_cu_budget)
+            budget = int(os.environ.get("MI3D_COMM_CUS", "0")) if do_comm else 0
+            in_flight = False
             for seg in range(nseg):
                 last = seg == nseg - 1
                 exch = st["comm_after"].get(seg) if do_comm else None
                 if last or exch:
+                    if budget and in_flight:
+                        call("mi3d_set_cu_budget", budget)
                     call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
                          ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
                          self._events)
+                    if budget and in_flight:
+                        call("mi3d_set_cu_budget", 0)
+                    in_flight = in_flight or bool(exch)
                     start = seg + 1
-                    if exch:
+                    if exch and not last:
                         with_met, met_pending = met_pending, False
                         comm(lambda b=tuple(exch), wm=with_met: self._on_comm_stream(
                             lambda: ([self.comm.average_(met)] if wm else []) + [self.comm.reduce_bucket(k) for k in b]))
+                    elif exch:
+                        # the exchange behind the LAST segment has nothing left to hide under: it runs on the compute stream
+                        # itself, after the join with the exchange stream (collectives of one communicator never overlap each
+                        # other) -- one fork / join pair per step instead of two (a cross-queue dependency costs ~12 us)
+                        with_met, met_pending = met_pending, False
+                        joined = True
+                        comm(self._join_comm)
+                        comm(lambda b=tuple(exch), wm=with_met: ([self.comm.average_(met)] if wm else []) +
+                             [self.comm.reduce_bucket(k) for k in b])
         if met_pending:
             comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
-        if self.do_comm:
+        if self.do_comm and not joined:
             comm(self._join_comm)
         if boundary:
             self._adamw(self.arena, st["opt_ranges"], self._hyper(), s)
