@@ -235,7 +235,7 @@ def main():
         torch.manual_seed(3)
         disc = DomainDiscriminator(256).to(dev).train()
         ts = DannStep(model, disc, loss="ce_tversky", lambda_domain=0.2, lr=1e-3, weight_decay=0.01, compute_dtype=cdt,
-                      use_graph=use_graph)
+                      use_graph=use_graph, overlap_forwards=not a.serial_forwards)
         xt, _ = synth(a.batch, a.size, 4321 + rank)
         ts.load_batch(x.clamp(0, 1).to(dev), y.to(dev), ((xt - xt.min()) / (xt.max() - xt.min())).to(dev))
     else:

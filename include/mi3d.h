@@ -64,12 +64,19 @@ size_t mi3d_unet_workspace_bytes(const mi3d_unet_desc* d);
 int64_t mi3d_unet_dropout_count(const mi3d_unet_desc* d);
 
 /* training != 0: batch statistics + running-stat update (BN train mode); == 0: running stats (eval mode).
+ * training == 2: batch statistics with the running-stat update DEFERRED -- buffers[i] of every running_mean slot then points
+ * at a device double[2*C] side buffer (the running_var / num_batches_tracked slots are ignored) into which the forward
+ * publishes (batch mean, unbiased batch variance); mi3d_unet_bn_apply_deferred applies them to the real buffers later.  For
+ * two forwards of ONE model on two streams (train_dann.py:268-272: source then target): the second one's updates of the
+ * shared buffers are applied after both have run, in the reference's order, bit-identically to the serial execution.
  * drop_scales: device float[mi3d_unet_dropout_count] holding 0 or 1/(1-p), or NULL (p = 0 / eval).
  * logits: device float (N,out_channels,D,H,W).  gap_out: device float (N, 2*features[L-1]) or NULL
  * (unet_dann.py:77-79).  The workspace keeps everything backward needs until the next forward. */
 int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
                       const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+int mi3d_unet_bn_apply_deferred(const mi3d_unet_desc* d, void* const* buffers, const void* const* side, void* stream);
 
 /* Inference forward (eval mode, no backward possible afterwards).  Replaces model.eval() + forward of
  * train_unet.py:259-305 (evaluate), test_model.py:242-251 and the frozen teacher of distill_unet.py:109-111,216-220:

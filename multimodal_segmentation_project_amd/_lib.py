@@ -52,6 +52,7 @@ _SIGS = {
     "mi3d_unet_segment_params": (i32, [_DP, i32, C.POINTER(C.c_int)]),
     "mi3d_unet_forward": (i32, [_DP, vp, vp, vp, vp, i32, vp, vp, vp, sz, vp]),
     "mi3d_unet_infer": (i32, [_DP, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mi3d_unet_bn_apply_deferred": (i32, [_DP, vp, vp, vp]),
     "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp]),
     "mi3d_event_create": (i32, [C.POINTER(vp)]),
     "mi3d_event_destroy": (i32, [vp]),

@@ -132,12 +132,17 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
         stat[C + c] = (float)inv;
         stat[2 * C + c] = a;
         stat[3 * C + c] = (float)((double)beta[c] - mean * (double)gamma[c] * inv);
-        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-        if (running_var) {
-            double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        if (momentum < 0.f) {          // deferred running-statistics update (ops.h bn_deferred_apply): publish the doubles
+            double* side = reinterpret_cast<double*>(running_mean);
+            if (side) { side[c] = mean; side[C + c] = M > 1 ? var * (double)M / (double)(M - 1) : var; }
+        } else {
+            if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            if (running_var) {
+                double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            }
+            if (nbt && c == 0) *nbt += 1;
         }
-        if (nbt && c == 0) *nbt += 1;
     }
 }
 
@@ -209,12 +214,17 @@ __device__ __forceinline__ void bn_train_coeffs(const BnPart& t, int C, float* s
             stat[C + c] = (float)inv;
             stat[2 * C + c] = a;
             stat[3 * C + c] = b;
-            if (t.running_mean) t.running_mean[c] = (float)((1.0 - t.momentum) * t.running_mean[c] + t.momentum * mean);
-            if (t.running_var) {
-                double unb = t.M > 1 ? var * (double)t.M / (double)(t.M - 1) : var;
-                t.running_var[c] = (float)((1.0 - t.momentum) * t.running_var[c] + t.momentum * unb);
+            if (t.momentum < 0.f) {      // deferred running-statistics update: publish the doubles
+                double* side = reinterpret_cast<double*>(t.running_mean);
+                if (side) { side[c] = mean; side[C + c] = t.M > 1 ? var * (double)t.M / (double)(t.M - 1) : var; }
+            } else {
+                if (t.running_mean) t.running_mean[c] = (float)((1.0 - t.momentum) * t.running_mean[c] + t.momentum * mean);
+                if (t.running_var) {
+                    double unb = t.M > 1 ? var * (double)t.M / (double)(t.M - 1) : var;
+                    t.running_var[c] = (float)((1.0 - t.momentum) * t.running_var[c] + t.momentum * unb);
+                }
+                if (t.nbt && c == 0) *t.nbt += 1;
             }
-            if (t.nbt && c == 0) *t.nbt += 1;
         }
     }
     __syncthreads();
@@ -526,6 +536,16 @@ __global__ void bn_fold_all_kernel(BnFoldJobs J) {
     }
 }
 
+// the deferred running-statistics updates of a whole network in one launch (block = one BatchNorm layer)
+__global__ void bn_deferred_apply_kernel(BnDeferJobs J) {
+    const BnDeferJob& j = J.j[blockIdx.x];
+    for (int c = threadIdx.x; c < j.C; c += blockDim.x) {
+        j.rm[c] = (float)((1.0 - J.momentum) * j.rm[c] + J.momentum * j.side[c]);
+        j.rv[c] = (float)((1.0 - J.momentum) * j.rv[c] + J.momentum * j.side[j.C + c]);
+    }
+    if (threadIdx.x == 0 && j.nbt) *j.nbt += 1;
+}
+
 inline bool vec8_ok(int C, int cs_a, int cs_b, const void* pa, const void* pb, int esz) {
     return C % 8 == 0 && cs_a % 8 == 0 && cs_b % 8 == 0 && ((uintptr_t)pa % 16 == 0) && ((uintptr_t)pb % 16 == 0) &&
            (C / 8) <= BLK && esz > 0;
@@ -703,6 +723,13 @@ int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, 
     MI3D_LAUNCH_CHECK();
     if (small) { *small_rows = nblk; return 0; }
     bn_stats_finalize_kernel<<<C, FIN_T, 0, s>>>(ws, nblk, C, M, gamma, beta, running_mean, running_var, nbt, momentum, eps, stat);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_deferred_apply(const BnDeferJobs& J, hipStream_t s) {
+    MI3D_CHECK_ARG(J.n >= 1 && J.n <= MAX_FOLD_JOBS && J.momentum >= 0.f, "bn_deferred_apply: bad job list");
+    bn_deferred_apply_kernel<<<J.n, 256, 0, s>>>(J);
     MI3D_LAUNCH_CHECK();
     return 0;
 }

@@ -111,6 +111,14 @@ struct BnFoldJob { const float* gamma; const float* beta; const float* rm; const
 constexpr int MAX_FOLD_JOBS = 2 * (2 * 6 + 1);
 struct BnFoldJobs { int n; float eps; BnFoldJob j[MAX_FOLD_JOBS]; };
 int bn_fold_all(const BnFoldJobs& J, hipStream_t s);
+// DEFERRED running-statistics update: a training forward called with momentum < 0 does not touch running_mean / running_var /
+// num_batches_tracked; `running_mean` then points at double[2C] where the finalize step publishes (batch mean, unbiased batch
+// variance) exactly as it computed them.  bn_deferred_apply performs, later and in the order the caller chooses, the very
+// update the forward would have made -- same doubles, same expression, bit-identical buffers.  (Two forwards of one model
+// on two streams, train_dann.py:268-272: their updates of the shared buffers must stay in source-then-target order.)
+struct BnDeferJob { float* rm; float* rv; int64_t* nbt; const double* side; int C; };
+struct BnDeferJobs { int n; float momentum; BnDeferJob j[MAX_FOLD_JOBS]; };
+int bn_deferred_apply(const BnDeferJobs& J, hipStream_t s);
 // z = drop[n,c] * relu(a*y + b)      (drop == NULL -> 1)
 // small != NULL: batch statistics from small->part (prologue); stat[4][C] is then WRITTEN (kept for backward) and the
 // running statistics / num_batches_tracked are updated here

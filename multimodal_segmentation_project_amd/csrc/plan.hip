@@ -251,6 +251,9 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         float* rm = buffers ? (float*)buffers[H.bidx] : nullptr;
         float* rv = buffers ? (float*)buffers[H.bidx + 1] : nullptr;
         int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
+        // training == 2: deferred running-statistics update -- buffers[bidx] is a double[2C] side buffer (ops.h bn_deferred_apply)
+        const float mom = training == 2 ? -1.f : p.d.bn_momentum;
+        if (training == 2) { rv = nullptr; nbt = nullptr; }
         bool fused_stats = false, nosplit = false;
         int nosplit_rows = 0;
         void* zo = h == 0 ? c.at(B.z1) : zout;
@@ -285,19 +288,19 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         if (nosplit) small_rows = nosplit_rows;
         else if (fused_stats) {
             MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
-                                       c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.s));
+                                       c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps, c.at<float>(H.stat), c.s));
         } else if (training && ksd > 0) {
             MI3D_TRY(bn_train_stats_splitk(c.at<float>(p.skws), ksd, c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2),
-                                           c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat),
+                                           c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps, c.at<float>(H.stat),
                                            c.at<float>(p.bnws), c.s, &small_rows));
         } else if (training) {
             MI3D_TRY(bn_train_stats(p.dt, c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt,
-                                    p.d.bn_momentum, p.d.bn_eps, c.at<float>(H.stat), c.at<float>(p.bnws), c.s, &small_rows));
+                                    mom, p.d.bn_eps, c.at<float>(H.stat), c.at<float>(p.bnws), c.s, &small_rows));
         } else {
             MI3D_CHECK_ARG(rm && rv, "eval-mode forward needs running statistics");
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
-        BnSmall sm{nosplit ? c.at<float>(p.statpart) : c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, p.d.bn_momentum, p.d.bn_eps};
+        BnSmall sm{nosplit ? c.at<float>(p.statpart) : c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps};
         if (h == 1 && pooled)
             MI3D_TRY(bn_apply_relu_drop_pool(p.dt, c.at(H.y), H.Cout, H.Cout, g, c.at<float>(H.stat),
                                              (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, pooled, pcs, c.s,
@@ -527,6 +530,22 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
     MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
                        d->out_channels, d->N, p.geo[0].V(), c.s));
     return 0;
+}
+
+int mi3d_unet_bn_apply_deferred(const mi3d_unet_desc* d, void* const* buffers, const void* const* side, void* stream) {
+    Plan p;
+    MI3D_TRY(build_plan(d, p));
+    MI3D_CHECK_ARG(buffers && side, "mi3d_unet_bn_apply_deferred: null pointer");
+    BnDeferJobs J;
+    J.n = 0; J.momentum = d->bn_momentum;
+    for (int b = 0; b < p.nblk; b++)
+        for (int h = 0; h < 2; h++) {
+            const HalfP& H = p.blk[b].h[h];
+            MI3D_CHECK_ARG(buffers[H.bidx] && buffers[H.bidx + 1] && side[H.bidx], "mi3d_unet_bn_apply_deferred: missing buffer %d", H.bidx);
+            J.j[J.n++] = BnDeferJob{(float*)buffers[H.bidx], (float*)buffers[H.bidx + 1], (int64_t*)buffers[H.bidx + 2],
+                                    (const double*)side[H.bidx], H.Cout};
+        }
+    return bn_deferred_apply(J, (hipStream_t)stream);
 }
 
 int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,

@@ -596,9 +596,14 @@ class DannStep(_StepBase):
 
     def __init__(self, seg_model, disc_model, loss="ce_tversky", lambda_domain=0.1, lr=1e-3, weight_decay=0.01,
                  betas=(0.9, 0.999), eps=1e-8, grad_accum=1, process_group=None, compute_dtype=None, use_graph=False,
-                 force_comm=False):
+                 force_comm=False, overlap_forwards=True):
         self._init_common(seg_model, lr, weight_decay, betas, eps, grad_accum, process_group, compute_dtype, use_graph,
                           force_comm)
+        # The target forward does not depend on the source forward (train_dann.py:268-272): it runs on its own stream beside it.
+        # Both are forwards of ONE model in train mode, i.e. both update the same BatchNorm running statistics, source first:
+        # the target forward runs with the update DEFERRED (mi3d_unet_forward training = 2 publishes its batch statistics as
+        # doubles) and mi3d_unet_bn_apply_deferred applies it after the join -- buffers bit-identical to the serial order.
+        self.fwd_stream = concurrent_stream(self.device) if overlap_forwards else None
         self.disc = disc_model
         self.lam = float(lambda_domain)
         self.cfg = _loss_cfg(loss)
@@ -685,7 +690,19 @@ class DannStep(_StepBase):
         st["dlabels"] = torch.cat([torch.zeros(n, dtype=torch.int64), torch.ones(n, dtype=torch.int64)]).to(dev)
         st["ptab"] = ptr_table([p.data_ptr() for p in self.arena.params])
         st["gtab"] = ptr_table(self.arena.grad_ptrs())
-        st["btab"] = ptr_table([b.data_ptr() for b in self.model.buffers()])
+        bufs = list(self.model.buffers())
+        st["btab"] = ptr_table([b.data_ptr() for b in bufs])
+        # side buffers of the deferred BatchNorm update: double[2C] per layer, addressed through the running_mean slots
+        rms = [b for i, b in enumerate(bufs) if i % 3 == 0]
+        st["side"] = torch.zeros(sum(2 * b.numel() for b in rms), dtype=torch.float64, device=dev)
+        side_ptrs, off = [], 0
+        for i, b in enumerate(bufs):
+            if i % 3 == 0:
+                side_ptrs.append(st["side"].data_ptr() + 8 * off)
+                off += 2 * b.numel()
+            else:
+                side_ptrs.append(None)
+        st["btab_side"] = ptr_table(side_ptrs)
         st["opt_ranges"] = [(0, self.arena.numel)]
         self._statics[key] = st
         self._static = st
@@ -714,10 +731,20 @@ class DannStep(_StepBase):
             drop_s, drop_t = st["drop_s"], st["drop_t"]
         feat = st["feat"]
         F = feat.shape[1]
+        fs = self.fwd_stream
+        if fs is not None:
+            fs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(fs):
+                call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab_side"], ptr(drop_t), 2,
+                     ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], fs.cuda_stream)
         call("mi3d_unet_forward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1,
              ptr(st["logits"]), feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
-        call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab"], ptr(drop_t), 1,
-             ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], s)
+        if fs is not None:
+            torch.cuda.current_stream().wait_stream(fs)
+            call("mi3d_unet_bn_apply_deferred", C.byref(desc), st["btab"], st["btab_side"], s)
+        else:
+            call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab"], ptr(drop_t), 1,
+                 ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], s)
         call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
              C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
              ptr(st["met_ws"]), s)

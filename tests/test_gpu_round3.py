@@ -273,3 +273,58 @@ def test_round2_routes_are_invisible_at_the_headline_shape(monkeypatch):
             worst, wk = e, k
     print("MI3D_NO_SMALL_BN at 96^3: logits relerr", eo, "worst per-tensor gradient relerr", worst, wk)
     assert worst < 0.5, (wk, worst)
+
+
+def test_two_stream_forwards_are_bitwise_the_serial_order():
+    """Configs 4 and 5: the two independent forwards of a step run on two streams (DannStep: source || target with the target's
+    BatchNorm running-statistics update deferred and applied after the join; TrainStep distillation: student || frozen teacher).
+    Everything a step leaves behind -- metrics, parameters after AdamW, gradients, BatchNorm buffers incl. num_batches_tracked
+    -- must equal the serial order bit for bit, eagerly and under graph capture."""
+    from multimodal_segmentation_project_amd import unet_dann
+    from multimodal_segmentation_project_amd.dann import DomainDiscriminator
+    from multimodal_segmentation_project_amd.trainer import DannStep, TrainStep
+    xs, ys = _synth(2, 32, 11)
+    xt, _ = _synth(2, 32, 12, blocky=False)
+
+    def dann(overlap, graph):
+        torch.manual_seed(0)
+        seg = unet_dann.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+        torch.manual_seed(3)
+        disc = DomainDiscriminator(256).to(DEV).train()
+        for mod in disc.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        ts = DannStep(seg, disc, loss="combined", lambda_domain=0.2, compute_dtype=torch.bfloat16, use_graph=graph,
+                      overlap_forwards=overlap)
+        mets = [ts.step(xs.to(DEV), ys.to(DEV), xt.to(DEV)).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        return mets, ts.arena.p.clone(), ts.arena.g.clone(), ts.disc_arena.p.clone(), [b.clone() for b in seg.buffers()]
+
+    ref = dann(False, False)
+    for overlap, graph in ((True, False), (True, True)):
+        got = dann(overlap, graph)
+        for a, b in zip(ref[0], got[0]):
+            assert torch.equal(a, b), (overlap, graph)
+        for a, b in zip(ref[1:4], got[1:4]):
+            assert torch.equal(a, b), (overlap, graph)
+        for a, b in zip(ref[4], got[4]):
+            assert torch.equal(a, b), (overlap, graph)
+    assert int(ref[4][2]) == 6                    # two forwards per step x three steps
+
+    def distill(overlap, graph):
+        torch.manual_seed(0)
+        student = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+        torch.manual_seed(1)
+        teacher = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).eval()
+        ts = TrainStep(student, kd_teacher=teacher, kd_alpha=0.7, kd_temperature=2.0, compute_dtype=torch.bfloat16, use_graph=graph,
+                       overlap_teacher=overlap)
+        mets = [ts.step(xs.to(DEV), ys.to(DEV)).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        return mets, ts.arena.p.clone(), ts.arena.g.clone()
+
+    ref = distill(False, False)
+    for overlap, graph in ((True, False), (True, True)):
+        got = distill(overlap, graph)
+        for a, b in zip(ref[0], got[0]):
+            assert torch.equal(a, b), (overlap, graph)
+        assert torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2]), (overlap, graph)
