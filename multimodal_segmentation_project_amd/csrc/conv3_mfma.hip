@@ -1318,17 +1318,19 @@ template <bool BIG, bool SPLITK>
 __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char fused_lds[];       // one block for either body
     int nw = a.wgx * a.wgy * a.wgz, nwp = (nw + 7) & ~7;        // input-gradient workgroups start on XCD 0 again
+    int nd = a.dgx * a.dgy * a.dgz;
     int b = blockIdx.x;
-    if (b < nw) {
-        // the (co-block, ci-block) workgroups of one spatial slab re-read the same x / dy tiles: make them neighbours on ONE
-        // XCD ((y,z) fastest inside an XCD-contiguous run) so the re-reads hit that L2 instead of HBM (measured 5.7x the
-        // algorithmic bytes for 64->32 at 48^3 with slab-major order)
+    // weight-gradient workgroups FIRST: they are the long pole (measured round 3: input-gradient first +23 us/step, the two
+    // kinds interleaved in runs of 8 +57 us/step)
+    bool is_w = b < nwp;
+    if (!is_w) b -= nwp;
+    if (is_w ? b >= nw : b >= nd) return;
+    if (is_w) {
         int f = xcd_contig(b, nw), G = a.wgy * a.wgz, yz = f % G;
         Bid v{f / G, yz % a.wgy, yz / a.wgy, a.wgx, a.wgy, a.wgz};
         conv3_wgrad_body<1, 1, 27>(v, a.wx, a.wxcs, a.wCin, a.wdy, a.wdycs, a.wCout, a.N, a.D, a.H, a.W, a.tZ, a.tY, a.tX, 1, a.slabs,
                                    Halves());
-    } else if (b >= nwp) {
-        b -= nwp;
+    } else {
         if constexpr (BIG) {
             // both output-channel groups of a tile side by side on one XCD, tiles in XCD-contiguous runs
             int f = xcd_contig(b, a.dgx * a.dgy);
@@ -1577,7 +1579,7 @@ __global__ __launch_bounds__(BLK) void bwd_tail_kernel(TailArgs a) {
 
 struct WgCfg { int cob, cib, nt, tg, nsb; };
 
-inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
+inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g, int target = 0) {
     WgCfg c;
     // One co block x one ci block x all 27 taps per workgroup (108 accumulator registers + register prefetch of the
     // next tile = 248 VGPRs, 51 KB LDS -> 2 workgroups per CU).  Measured against fatter register blockings
@@ -1590,7 +1592,7 @@ inline WgCfg wgrad_cfg(int Cin, int Cout, Geo g) {
     c.nt = 27;
     c.tg = 1;
     // persistent: one round of workgroups, 2 per CU
-    int64_t want = 2 * persist_cus() / (int64_t)groups;
+    int64_t want = (target > 0 ? target : 2 * persist_cus()) / (int64_t)groups;
     if (want < 1) want = 1;
     int64_t rounds = cdiv(ntiles, want);               // tiles per workgroup; then the fewest slabs that keep it
     c.nsb = (int)cdiv(ntiles, rounds);
@@ -1732,7 +1734,12 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     if (ks_deferred) *ks_deferred = 0;
     MI3D_CHECK_ARG(conv3_mfma_bwd_fused_ok(Cin, Cout, xcs, dycs, dxcs, g) && dx && ((uintptr_t)dx % 16) == 0 && skws,
                    "conv3_mfma_bwd_fused: unsupported layer %d->%d", Cin, Cout);
-    WgCfg c = wgrad_cfg(Cin, Cout, g);
+    // the weight-gradient half shares the launch (and the CUs' two workgroup slots) with the input-gradient half: sized for
+    // ~288 workgroups instead of the stand-alone kernel's 512 it leaves fewer, fatter slabs (less slab traffic to sum) and lets
+    // the input-gradient workgroups start earlier.  Scan at 96^3 (tools/abenv.py, ms/step): 64: 2.71, 128: 2.42, 192: 2.33,
+    // 256: 2.32, 288: 2.286, 320: 2.288, 352: 2.296, 384: 2.303, 448: 2.309, 512: 2.313.  MI3D_FUSED_WG_TARGET overrides
+    const char* e_t = getenv("MI3D_FUSED_WG_TARGET");
+    WgCfg c = wgrad_cfg(Cin, Cout, g, e_t ? atoi(e_t) : 288);
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
     MI3D_CHECK_ARG(wgws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_bwd_fused: workspace too small");
     bool big = big_geo(g);

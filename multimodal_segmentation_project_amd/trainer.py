@@ -322,7 +322,7 @@ class TrainStep(_StepBase):
         # serial order.  Both forwards are long chains that leave most CUs idle at the deep levels, so they interleave.
         self.kd_stream = concurrent_stream(self.device) if (kd_teacher is not None and overlap_teacher) else None
         # second compute stream: weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
-        self.aux_stream = torch.cuda.Stream(device=self.device) if two_stream else None
+        self.aux_stream = concurrent_stream(self.device) if two_stream else None
         self._events = None
         self._event_handles = []
         if two_stream:
