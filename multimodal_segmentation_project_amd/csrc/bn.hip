@@ -151,7 +151,13 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
 // every kernel node is a link of the step's dependent chain (~5 us each at these sizes), and an in-kernel "last workgroup
 // finalizes" ticket costs as much as the launch it replaces on 8 XCDs (measured).  Workgroup 0 publishes stat[4][C] for the
 // backward pass and updates the running statistics.
-constexpr int SMALL_ROWS = 128;
+constexpr int SMALL_ROWS_MAX = 512;
+static int small_rows_cap() {          // MI3D_SMALL_ROWS: A/B knob (tools/abenv.py); default 128
+    const char* e = getenv("MI3D_SMALL_ROWS");
+    int v = e ? atoi(e) : 128;
+    return v < 8 ? 8 : (v > SMALL_ROWS_MAX ? SMALL_ROWS_MAX : v);
+}
+#define SMALL_ROWS (small_rows_cap())
 constexpr int MAXC_BN = 256;
 struct BnPart {
     const float* part; int nrows; int64_t M;

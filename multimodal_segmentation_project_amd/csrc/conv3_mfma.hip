@@ -938,12 +938,13 @@ inline bool big_geo(Geo g) { return g.W >= 32 && g.H >= 16; }
 
 // K-split factor: only for the small-geometry configuration, when the (tile x cout-group) grid is below ~one
 // workgroup per CU; power of two dividing the chunk count
-inline int pick_ksplit(int Cin, int Cout, Geo g) {
+inline int pick_ksplit(int Cin, int Cout, Geo g, int target_override = 0) {
     if (big_geo(g)) return 1;
     int64_t wgs = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 8) * (Cout / (Cout % 32 == 0 ? 32 : 16));
     int nchunk = Cin / 16, k = 1;
     static const int target = getenv("MI3D_KS_TARGET") ? atoi(getenv("MI3D_KS_TARGET")) : 256;
-    while (wgs * k < target && k * 2 <= nchunk && nchunk % (k * 2) == 0 && k < 16) k *= 2;
+    const int tgt = target_override > 0 ? target_override : target;
+    while (wgs * k < tgt && k * 2 <= nchunk && nchunk % (k * 2) == 0 && k < 16) k *= 2;
     return k;
 }
 
@@ -1743,7 +1744,12 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
     MI3D_CHECK_ARG(wgws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_bwd_fused: workspace too small");
     bool big = big_geo(g);
-    int ks = pick_ksplit(Cout, Cin, g);                    // dgrad: input channels = Cout, output channels = Cin (1 if big)
+    // split-K target of the input-gradient half: 128 workgroups instead of the stand-alone conv's 256 -- it runs beside the
+    // weight-gradient workgroups of the same launch (scan at 96^3, ms/step: 32: 2.33, 64: 2.294, 96: 2.282, 128: 2.259,
+    // 192: 2.260, 256: 2.284).  MI3D_KS_TARGET_BWD overrides (values above 256 would outgrow the planned split-K scratch)
+    const char* e_k = getenv("MI3D_KS_TARGET_BWD");
+    int kst = e_k ? atoi(e_k) : 128;
+    int ks = pick_ksplit(Cout, Cin, g, kst > 256 ? 256 : kst);   // dgrad: input channels = Cout, output channels = Cin (1 if big)
     FusedArgs a;
     a.wx = (const bf16*)x; a.wxcs = xcs; a.wCin = Cin; a.wdy = (const bf16*)dy; a.wdycs = dycs; a.wCout = Cout;
     a.tZ = cdiv(g.D, WTZ); a.tY = cdiv(g.H, WTY); a.tX = cdiv(g.W, WTX); a.slabs = wgws;
