@@ -151,13 +151,7 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ part, int nbl
 // every kernel node is a link of the step's dependent chain (~5 us each at these sizes), and an in-kernel "last workgroup
 // finalizes" ticket costs as much as the launch it replaces on 8 XCDs (measured).  Workgroup 0 publishes stat[4][C] for the
 // backward pass and updates the running statistics.
-constexpr int SMALL_ROWS_MAX = 512;
-static int small_rows_cap() {          // MI3D_SMALL_ROWS: A/B knob (tools/abenv.py); default 128
-    const char* e = getenv("MI3D_SMALL_ROWS");
-    int v = e ? atoi(e) : 128;
-    return v < 8 ? 8 : (v > SMALL_ROWS_MAX ? SMALL_ROWS_MAX : v);
-}
-#define SMALL_ROWS (small_rows_cap())
+constexpr int SMALL_ROWS = 128;        // round 3 scan (ms/step): 64: 2.330, 128: 2.283, 256: 2.288, 512: 2.307
 constexpr int MAXC_BN = 256;
 struct BnPart {
     const float* part; int nrows; int64_t M;
@@ -558,7 +552,7 @@ inline bool vec8_ok(int C, int cs_a, int cs_b, const void* pa, const void* pb, i
 }
 
 inline int reduce_grid(int64_t M, int R) {
-    int64_t want = (M + (int64_t)R * 4 - 1) / ((int64_t)R * 4);       // ~4 rows per thread ...
+    int64_t want = (M + (int64_t)R * 4 - 1) / ((int64_t)R * 4);       // ~4 rows per thread (round 3: 2 and 8 measured neutral) ...
     int64_t one = (M + R - 1) / R;                                      // ... but small tensors (deep levels) are a latency
     if (want < 256) want = one < 256 ? one : 256;                       // chain, not a stream: one row per thread then
     if (want < 1) want = 1;
@@ -568,7 +562,7 @@ inline int reduce_grid(int64_t M, int R) {
 inline int stream_grid(int64_t total, int G) {
     int64_t want = (total + BLK - 1) / BLK;
     if (want < 1) want = 1;
-    if (want > 256 * 8) want = 256 * 8;
+    if (want > 256 * 8) want = 256 * 8;          // round 3: 1024 / 4096 workgroups measured neutral
     int m = 1;
     while ((m * BLK) % G != 0) m++;            // G = 5 -> m = 5, powers of two -> m = 1
     want = (want + m - 1) / m * m;

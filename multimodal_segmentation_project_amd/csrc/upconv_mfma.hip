@@ -432,7 +432,7 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         while (gx * gy < 512 && gy < Cin / 16) gy *= 2;
         int64_t gkx = cdiv(g.M(), 16);
         bool ksp = gx * gy < 512 && Cout / 4 >= 8 && gkx * (Cin / 16) <= 8192;
-        const int wcap = 256, dcap = 256;                    // one workgroup of each kind per CU (measured best)
+        const int wcap = 256, dcap = 256;                    // one workgroup of each kind per CU (measured best; round 3: 128 / 512 of either: neutral to +20 us)
         int groups = (Cin / 32) * (int)cdiv(Cout, 32);
         int64_t ntile = (g.M() + UV - 1) / UV;
         int64_t want = cdiv((int64_t)wcap, (int64_t)groups);
