@@ -186,9 +186,7 @@ int mi3d_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
                     float eps, float weight_decay, float grad_scale, int64_t* step_dev, void* stream);
 /* Same update over ONE contiguous range of the arena without (increment = 0) or with the step increment: a step over
  * several trainable ranges (frozen encoder, train_unet.py:31-43,413-431) = one call per range, increment on the last;
- * n = 0 with increment = 1 only advances the counter.  increment = 2 (n > 0): step_dev points at int64[2] = {step, 0}: the
- * increment rides in the update kernel (its last block to finish advances the counter; word 1 is a ticket that returns to
- * zero) instead of a one-thread launch of its own. */
+ * n = 0 with increment = 1 only advances the counter. */
 int mi3d_adamw_apply(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float grad_scale, int64_t* step_dev, int increment, void* stream);
 /* Dropout3d (unet.py:14,18) channel masks: out[i] = 0 w.p. p else 1/(1-p); state_dev = device uint64[2]

@@ -254,25 +254,19 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
         // training == 2: deferred running-statistics update -- buffers[bidx] is a double[2C] side buffer (ops.h bn_deferred_apply)
         const float mom = training == 2 ? -1.f : p.d.bn_momentum;
         if (training == 2) { rv = nullptr; nbt = nullptr; }
-        bool fused_stats = false, nosplit = false;
-        int nosplit_rows = 0;
+        bool fused_stats = false;
         void* zo = h == 0 ? c.at(B.z1) : zout;
         int zocs = h == 0 ? H.Cout : zcs;
         int ksd = 0, c1_blocks = 0;
         if (H.mfma) {
             if (!c.packed) MI3D_TRY(conv3_mfma_pack(c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), g, c.s));
-            // training: a split-K launch leaves its finishing pass to the statistics kernel (ksd = split factor)
-            // deep levels in training: no split-K when the tile grid alone leaves few enough statistic rows for the apply
-            // kernel to finish (conv with fused partial sums -> apply: two launches instead of conv, split-K finish +
-            // statistics, apply)
-            int nsb = conv3_mfma_stat_blocks(H.Cin, H.Cout, g);
-            nosplit = training && !conv3_mfma_fuses_stats(H.Cin, H.Cout, g) && bn_small_ok(H.Cout, g.M(), nsb) &&
-                      getenv("MI3D_FWD_NOSPLIT");
+            // training: a split-K launch leaves its finishing pass to the statistics kernel (ksd = split factor).  (Deep levels
+            // WITHOUT split-K -- conv with fused partial sums -> apply, two launches instead of three -- measured +0.10 ms in
+            // round 2: the 8-16-chunk K loops on 32-216 workgroups cost more than the launch they save; that route is gone.)
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
-                                    training ? c.at<float>(p.statpart) : nullptr, nosplit ? nullptr : c.at<float>(p.skws), c.s,
+                                    training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
                                     (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr));
-            fused_stats = training && (nosplit || conv3_mfma_fuses_stats(H.Cin, H.Cout, g));
-            if (nosplit) nosplit_rows = nsb;
+            fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
         } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT") &&
                    !getenv("MI3D_NO_C1_MFMA")) {
             // first layer on the matrix cores (taps are the K dimension), BN partial sums fused like the other convs
@@ -285,8 +279,7 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
                                       H.Cout, g, c.s));
         }
         int small_rows = 0;      // deep levels: the statistics' few partial rows are finished by the apply kernel (no finalize launch)
-        if (nosplit) small_rows = nosplit_rows;
-        else if (fused_stats) {
+        if (fused_stats) {
             MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
                                        c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps, c.at<float>(H.stat), c.s));
         } else if (training && ksd > 0) {
@@ -300,7 +293,7 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             MI3D_CHECK_ARG(rm && rv, "eval-mode forward needs running statistics");
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
-        BnSmall sm{nosplit ? c.at<float>(p.statpart) : c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps};
+        BnSmall sm{c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps};
         if (h == 1 && pooled)
             MI3D_TRY(bn_apply_relu_drop_pool(p.dt, c.at(H.y), H.Cout, H.Cout, g, c.at<float>(H.stat),
                                              (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, pooled, pcs, c.s,

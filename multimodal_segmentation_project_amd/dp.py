@@ -30,8 +30,7 @@ class ParamArena:
         self.g = torch.zeros(off, dtype=torch.float32, device=device)
         self.m = torch.zeros(off, dtype=torch.float32, device=device)
         self.v = torch.zeros(off, dtype=torch.float32, device=device)
-        self._step2 = torch.zeros(2, dtype=torch.int64, device=device)      # {step, ticket word of mi3d_adamw_apply(increment=2)}
-        self.step = self._step2[:1]
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.p[o:o + p.numel()].view(p.shape)

@@ -127,6 +127,7 @@ def get_loss_fn(loss_type):
 
 
 # ---- metrics: one pass for all three, shared through a 1-entry cache ---------------------------------------
+import os
 import weakref
 
 _cache = {"pred": None, "target": None, "ver": None, "val": None}
@@ -138,6 +139,14 @@ def _cache_key(pred, target):
     return (pred._version, target._version, pred.data_ptr(), target.data_ptr(), _lib.launches)
 
 
+def invalidate_metrics_cache():
+    """Drop the shared (iou, dice, accuracy) result.  The cache key sees torch-side writes (tensor versions) and every call
+    made through this package (`_lib.call`); it cannot see a buffer rewritten behind both -- a user's own
+    torch.cuda.CUDAGraph.replay(), a direct `_lib.lib().mi3d_*` call, another library's kernel writing into a static logits
+    buffer.  Call this after such a write (or set MI3D_NO_METRICS_CACHE=1 to disable the sharing altogether)."""
+    _cache["pred"] = _cache["target"] = _cache["ver"] = _cache["val"] = None
+
+
 def calculate_all(pred, target):
     """(iou, dice, accuracy) as a float32 tensor[3] from ONE argmax+count pass [utils/metrics.py:65-129].
     The reference's three functions are called back to back on the same tensors (train_unet.py:229-232); the
@@ -146,7 +155,8 @@ def calculate_all(pred, target):
     n, c, v, labels = _prep(pred, target)
     cp = _cache["pred"]() if _cache["pred"] is not None else None
     ct = _cache["target"]() if _cache["target"] is not None else None
-    if cp is pred and ct is target and _cache["ver"] == _cache_key(pred, target):
+    if (cp is pred and ct is target and _cache["ver"] == _cache_key(pred, target)
+            and os.environ.get("MI3D_NO_METRICS_CACHE", "0") != "1"):
         return _cache["val"]
     p32 = pred.detach().contiguous().float()
     d = pred.shape[2] if pred.dim() > 2 else 1      # reference loop bound: first spatial dim after argmax

@@ -205,7 +205,7 @@ class _StepBase:
         for k, (lo, hi) in enumerate(ranges):
             call("mi3d_adamw_apply", arena.p.data_ptr() + 4 * lo, arena.g.data_ptr() + 4 * lo,
                  arena.m.data_ptr() + 4 * lo, arena.v.data_ptr() + 4 * lo, hi - lo, lr, b1, b2, eps, wd, 1.0,
-                 ptr(arena.step), 2 if k == len(ranges) - 1 else 0, s)      # 2: the step increment rides in the last update kernel
+                 ptr(arena.step), int(k == len(ranges) - 1), s)
 
     @staticmethod
     def _trainable_ranges(arena, trainable):
