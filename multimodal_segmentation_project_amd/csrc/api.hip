@@ -146,7 +146,7 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
     }
     if (dx && use_mfma(dy_dtype, dy_dtype, Cout, Cin, dycs, dxcs)) {
         MI3D_TRY(conv3_mfma_pack(w, Cin, Cout, wpf, wpd, g, s));
-        MI3D_TRY(conv3_mfma_fwd(dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, nullptr, nullptr, s));
+        MI3D_TRY(conv3_mfma_fwd(dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, nullptr, nullptr, s));      // skws NULL: single pass
     } else {
         MI3D_TRY(conv3_direct_pack(w, Cin, Cout, wpf, wpd, s));
         if (dx) MI3D_TRY(conv3_direct_fwd(dy_dtype, dy_dtype, dy, dycs, Cout, wpd, nullptr, dx, dxcs, Cin, g, s));

@@ -371,6 +371,193 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
                                                           tilesY, tilesX, part, nullptr, relu);
 }
 
+
+// ------------------------------------------------------------------------------------------ eight-wave forward variant
+// Levels 1-4 run ONE tile per workgroup with <= 2 workgroups per CU (432 tiles at level 1), so the serial chain of one
+// workgroup (tile loads -> LDS -> K loop -> stores) IS the kernel time.  This variant halves that chain per wave: 8 waves,
+// wave w owns z-slice w & 3 and HALF of the slice's M-blocks (w >> 2); staging is spread over 512 threads; the chunk's weight
+// fragments are staged through LDS once per workgroup (no per-wave register ring, no vector-memory wait inside the K loop),
+// which keeps the kernel under 128 VGPRs = 4 waves per SIMD.  Same arithmetic per output element as conv3_mfma_body (same
+// K order, same fp32 accumulation) -> bit-identical outputs; the statistic partials sum 8 instead of 4 wave rows.
+template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK>
+__global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+                                                          const bf16* __restrict__ wp, const float* __restrict__ bias,
+                                                          bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
+                                                          int tilesZ, int tilesY, int tilesX, float* __restrict__ part, int relu) {
+    constexpr int NT = 512;
+    constexpr int BY = 16 / BX;
+    constexpr int TY = TYB * BY, TX = TXB * BX;
+    constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
+    static_assert(TZ == 4, "one z-slice of the tile per wave pair");
+    constexpr int MB = TYB * TXB, MBW = MB / 2;          // M-blocks per slice / per wave
+    static_assert(MB % 2 == 0 && MBW <= 4, "two waves share a slice");
+    constexpr int NVOX = IZ * IY * IX;
+    extern __shared__ __attribute__((aligned(16))) char lds8[];
+    bf16* xs = reinterpret_cast<bf16*>(lds8);
+    bf16* wl = xs + NVOX * 16;                                   // [14][COB][64 lanes][8] of the current chunk
+    float (*red)[COB][16][2] = reinterpret_cast<float (*)[COB][16][2]>(lds8 + (NVOX * 16 + 14 * COB * 512) * 2);
+    Bid bid_ = real_bid();
+    int tile = xcd_contig(bid_.x, bid_.gx);
+    int tx_ = tile % tilesX; tile /= tilesX;
+    int ty_ = tile % tilesY; tile /= tilesY;
+    int tz_ = tile % tilesZ; int n = tile / tilesZ;
+    int z0 = tz_ * TZ, y0 = ty_ * TY, x0 = tx_ * TX;
+    int cobBase = bid_.y * COB;
+    int nCobTotal = CoutTotal / 16;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int zs = wave & 3, hb = wave >> 2;
+    int vn = lane & 15, g = lane >> 4;
+    int laneOff = (((vn / BX) * IX + (vn % BX)) * 16 + (g & 1) * 8) * 2 + zs * (IY * IX * 32);
+    const char* xsb = reinterpret_cast<const char*>(xs);
+    f32x4 acc[MBW][COB];
+#pragma unroll
+    for (int r = 0; r < MBW; r++)
+#pragma unroll
+        for (int c = 0; c < COB; c++) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NIT = (NVOX * 2 + NT - 1) / NT;
+    int soff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int idx = threadIdx.x + it * NT;
+        int vox = idx >> 1, half = idx & 1;
+        int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+        int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+        bool inb = idx < NVOX * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        soff[it] = inb ? ((gz * H + gy) * W + gx) * xcs + half * 8 : -1;
+    }
+    const bf16* xn = x + (int64_t)n * D * H * W * xcs;
+    int nchunk = Cin / 16, chunk0 = 0;
+    if (SPLITK) {
+        int per = nchunk / bid_.gz;
+        chunk0 = bid_.z * per;
+        nchunk = chunk0 + per;
+    }
+    bf16x8 sv[NIT];
+    constexpr int NWI = (14 * COB * 64 + NT - 1) / NT;
+    bf16x8 wv[NWI];
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + chunk * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; i++) {
+            int q = threadIdx.x + i * NT;
+            if (q < 14 * COB * 64) {
+                int f = q >> 6, s_ = f / COB, c_ = f - s_ * COB;
+                wv[i] = *reinterpret_cast<const bf16x8*>(wp + (((int64_t)chunk * 14 + s_) * nCobTotal + cobBase + c_) * 512 + (q & 63) * 8);
+            }
+        }
+    };
+    load_chunk(chunk0);
+    auto frag_off = [&](int s) {
+        int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
+        int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IX + (t0 % 3)) * 32;
+        int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IX + (t1 % 3)) * 32;
+        return laneOff + ((g >> 1) ? off1 : off0);
+    };
+    auto row_off = [&](int r) { int rg = hb * MBW + r; return (((rg / TXB) * BY) * IX + (rg % TXB) * BX) * 32; };
+    for (int chunk = chunk0; chunk < nchunk; chunk++) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            int idx = threadIdx.x + it * NT;
+            if (idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = sv[it];
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; i++) {
+            int q = threadIdx.x + i * NT;
+            if (q < 14 * COB * 64) *reinterpret_cast<bf16x8*>(wl + q * 8) = wv[i];
+        }
+        __syncthreads();
+        if (chunk + 1 < nchunk) load_chunk(chunk + 1);        // in flight under this chunk's K loop
+        bf16x8 xf[2][MBW];
+        {
+            int toff = frag_off(0);
+#pragma unroll
+            for (int r = 0; r < MBW; r++) xf[0][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(r));
+        }
+#pragma unroll
+        for (int s = 0; s < 14; s++) {
+            bf16x8 wcur[COB];
+#pragma unroll
+            for (int c = 0; c < COB; c++) wcur[c] = *reinterpret_cast<const bf16x8*>(wl + ((s * COB + c) * 64 + lane) * 8);
+            if (s + 1 < 14) {
+                int toff = frag_off(s + 1);
+#pragma unroll
+                for (int r = 0; r < MBW; r++) xf[(s + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(r));
+            }
+#pragma unroll
+            for (int r = 0; r < MBW; r++)
+#pragma unroll
+                for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wcur[c], xf[s & 1][r], acc[r][c]);
+        }
+    }
+    if constexpr (SPLITK) {
+        int64_t Mtot = (int64_t)(bid_.gx / (tilesZ * tilesY * tilesX)) * D * H * W;
+        float* pk = part + (int64_t)bid_.z * Mtot * CoutTotal;
+#pragma unroll
+        for (int r = 0; r < MBW; r++) {
+            int rg = hb * MBW + r;
+            int byb = rg / TXB, bxb = rg % TXB;
+            int gz = z0 + zs, gy = y0 + byb * BY + vn / BX, gx = x0 + bxb * BX + vn % BX;
+            if (gz < D && gy < H && gx < W) {
+                float* pp = pk + ((((int64_t)n * D + gz) * H + gy) * W + gx) * CoutTotal + cobBase * 16 + g * 4;
+#pragma unroll
+                for (int c = 0; c < COB; c++) *reinterpret_cast<f32x4*>(pp + c * 16) = acc[r][c];
+            }
+        }
+        return;
+    }
+    float s1[COB][4], s2[COB][4];
+#pragma unroll
+    for (int c = 0; c < COB; c++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) s1[c][j] = s2[c][j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < MBW; r++) {
+        int rg = hb * MBW + r;
+        int byb = rg / TXB, bxb = rg % TXB;
+        int gz = z0 + zs, gy = y0 + byb * BY + vn / BX, gx = x0 + bxb * BX + vn % BX;
+        bool ok = gz < D && gy < H && gx < W;
+        bf16* yp = y + ((((int64_t)n * D + gz) * H + gy) * W + gx) * ycs + cobBase * 16 + g * 4;
+#pragma unroll
+        for (int c = 0; c < COB; c++) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = acc[r][c][j] + (bias ? bias[(cobBase + c) * 16 + g * 4 + j] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);
+                o[j] = (bf16)v;
+                if (STATS && ok) { float q = (float)o[j]; s1[c][j] += q; s2[c][j] += q * q; }
+            }
+            if (ok) *reinterpret_cast<bf16x4*>(yp + c * 16) = o;
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int c = 0; c < COB; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float a = s1[c][j], b = s2[c][j];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (vn == 0) { red[wave][c][g * 4 + j][0] = a; red[wave][c][g * 4 + j][1] = b; }
+            }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < COB * 16 * 2; idx += NT) {
+            int k = idx & 1, ch = idx >> 1;
+            int c = ch / 16, cc = ch % 16;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; w++) v += red[w][c][cc][k];
+            part[((int64_t)bid_.x * 2 + k) * CoutTotal + cobBase * 16 + ch] = v;
+        }
+    }
+}
+constexpr size_t conv8_lds(int TY, int TX, int COB) { return (size_t)6 * (TY + 2) * (TX + 2) * 32 + (size_t)14 * COB * 1024 + (size_t)8 * COB * 16 * 2 * 4; }
+
 // ------------------------------------------------------------------------------------------ persistent variant
 // Full-resolution layers (16->16, 32->16, 16->32: 60 % of all conv FLOPs and most of the bytes).  Same math and tile
 // (4 x 8 x 16 voxels) as conv3_mfma_kernel, restructured around what the profile showed (instruction-issue bound,
@@ -864,6 +1051,7 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_dma_kernel(const bf
     }
 }
 
+constexpr bool CONV8_DEFAULT = true;        // round 3 A/B: level-1 forward convs 112 -> 103 us, deep 153 -> 143 us per step
 constexpr int PERSIST_WGS = 512;
 // CU budget (mi3d_set_cu_budget): CUs the caller wants left free of persistent workgroups because a collective kernel is
 // resident on them (data-parallel step: the gradient all-reduce runs beside the encoder backward).  A persistent grid sized
@@ -920,16 +1108,31 @@ int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bia
     constexpr int TY = TYB * (16 / BX), TX = TXB * BX;
     int tz = cdiv(g.D, TZ), ty = cdiv(g.H, TY), tx = cdiv(g.W, TX);
     dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)), (unsigned)ksplit);
+    // eight-wave variant (see conv3_mfma8_kernel); MI3D_CONV8=0 selects the four-wave kernels
+    static_assert((TYB * TXB) % 2 == 0, "tile shapes used here have an even number of M-blocks per slice");
+    const char* e8 = getenv("MI3D_CONV8");
+    const bool w8 = e8 ? atoi(e8) != 0 : CONV8_DEFAULT;
+    constexpr size_t lds8 = conv8_lds(TY, TX, COB);
+#define LC8(ST_, SK_, PART_, BIAS_, RELU_)                                                                                     \
+    do {                                                                                                                       \
+        MI3D_SET_MAX_LDS_ONCE((&conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, ST_, SK_>), lds8);                                   \
+        conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, ST_, SK_><<<grid, 512, lds8, s>>>(x, xcs, Cin, wp, BIAS_, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, PART_, RELU_); \
+    } while (0)
     if (ksplit > 1) {
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, nullptr, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, skws, 0);
+        if (w8) LC8(false, true, skws, nullptr, 0);
+        else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, nullptr, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, skws, 0);
         MI3D_LAUNCH_CHECK();
         if (defer_finish) return 0;
         int64_t tot = g.M() * (Cout / 8);
         splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ksplit, g.M(), Cout, bias, y, ycs, relu);
-    } else if (part)
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part, relu);
-    else
-        conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr, relu);
+    } else if (part) {
+        if (w8) LC8(true, false, part, bias, relu);
+        else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part, relu);
+    } else {
+        if (w8) LC8(false, false, nullptr, bias, relu);
+        else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr, relu);
+    }
+#undef LC8
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1009,8 +1212,14 @@ bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g) { return pick_ksplit(Cin, 
 // (only when conv3_mfma_fuses_stats); skws = K-split scratch (conv3_mfma_splitk_floats) or NULL to force single pass
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g) { return persist_ok(Cin, Cout, g); }
 
+int conv3_bwd_ks_target() {
+    const char* e_k = getenv("MI3D_KS_TARGET_BWD");
+    int kst = e_k ? atoi(e_k) : 128;
+    return kst > 256 ? 256 : (kst < 1 ? 1 : kst);
+}
+
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
-                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred, int relu) {
+                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred, int relu, int ks_target) {
     if (ks_deferred) *ks_deferred = 0;
     MI3D_CHECK_ARG((!xh.on() && !yh.on()) || persist_ok(Cin, Cout, g), "conv3_mfma_fwd: planar halves need the persistent kernel");
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, ycs), "conv3_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
@@ -1050,7 +1259,7 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         MI3D_LAUNCH_CHECK();
         return 0;
     }
-    int ks = skws ? pick_ksplit(Cin, Cout, g) : 1;
+    int ks = skws ? pick_ksplit(Cin, Cout, g, ks_target) : 1;
     if (ks > 1) MI3D_CHECK_ARG(ycs % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv3_mfma_fwd: split-K needs 16-B aligned output rows");
     if (big_geo(g)) {
         if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s, false, relu);
@@ -1747,9 +1956,7 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     // split-K target of the input-gradient half: 128 workgroups instead of the stand-alone conv's 256 -- it runs beside the
     // weight-gradient workgroups of the same launch (scan at 96^3, ms/step: 32: 2.33, 64: 2.294, 96: 2.282, 128: 2.259,
     // 192: 2.260, 256: 2.284).  MI3D_KS_TARGET_BWD overrides (values above 256 would outgrow the planned split-K scratch)
-    const char* e_k = getenv("MI3D_KS_TARGET_BWD");
-    int kst = e_k ? atoi(e_k) : 128;
-    int ks = pick_ksplit(Cout, Cin, g, kst > 256 ? 256 : kst);   // dgrad: input channels = Cout, output channels = Cin (1 if big)
+    int ks = pick_ksplit(Cout, Cin, g, conv3_bwd_ks_target());   // dgrad: input channels = Cout, output channels = Cin (1 if big)
     FusedArgs a;
     a.wx = (const bf16*)x; a.wxcs = xcs; a.wCin = Cin; a.wdy = (const bf16*)dy; a.wdycs = dycs; a.wCout = Cout;
     a.tZ = cdiv(g.D, WTZ); a.tY = cdiv(g.H, WTY); a.tX = cdiv(g.W, WTX); a.slabs = wgws;

@@ -52,7 +52,10 @@ struct Halves { int split = 1 << 30; int64_t delta = 0; bool on() const { return
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g);          // forward (Cin,Cout) launch can take Halves x / y
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
                    Geo g, float* part, float* skws, hipStream_t s, Halves xh = Halves(), Halves yh = Halves(),
-                   int* ks_deferred = nullptr, int relu = 0);
+                   int* ks_deferred = nullptr, int relu = 0, int ks_target = 0);
+// ks_target > 0: split-K workgroup target of this launch (0 = the forward default).  The input-gradient convs of the backward
+// use conv3_bwd_ks_target() in the fused launch AND when they run stand-alone, so both routes produce the same bits
+int conv3_bwd_ks_target();
 // relu != 0: y = max(0, conv + bias) -- the inference path, where BatchNorm is folded into (weights, bias)
 // ks_deferred != NULL: a split-K launch leaves its fp32 partials in skws ([ks][M][Cout]) WITHOUT the finishing pass and
 // reports ks there (0 = y was written as usual); the caller finishes (bn_train_stats_splitk, fused with the statistics)

@@ -383,7 +383,7 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             if (H.mfma)
                 MI3D_TRY(conv3_mfma_fwd(dyb, H.Cout, H.Cout, c.at(H.wpd), nullptr, dx, dxs, H.Cin, g, nullptr,
                                         (dxs % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s, Halves(),
-                                        (h == 0 && b > p.L) ? p.halves(B.level) : Halves()));
+                                        (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), nullptr, 0, conv3_bwd_ks_target()));
             else
                 MI3D_TRY(conv3_direct_fwd(p.dt, p.dt, dyb, H.Cout, H.Cout, c.at<float>(H.wpd), nullptr, dx, dxs, H.Cin, g, c.s));
         }

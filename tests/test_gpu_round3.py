@@ -328,3 +328,25 @@ def test_two_stream_forwards_are_bitwise_the_serial_order():
         for a, b in zip(ref[0], got[0]):
             assert torch.equal(a, b), (overlap, graph)
         assert torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2]), (overlap, graph)
+
+
+def test_eight_wave_conv_is_bit_identical_to_the_four_wave_kernel(monkeypatch):
+    """conv3_mfma8_kernel (levels 1-4 forward / stand-alone input gradient: 8 waves, weights through LDS) computes every output
+    element with the same K order and fp32 accumulation order as conv3_mfma_kernel -> identical bf16 outputs, ragged borders,
+    both tile shapes, split-K included (MI3D_CONV8=0 selects the four-wave kernels)."""
+    for (n, cin, cout, d, h, w) in [(2, 32, 32, 8, 16, 32), (1, 64, 32, 6, 17, 35), (2, 64, 64, 12, 12, 12), (1, 128, 256, 6, 6, 6),
+                                    (1, 16, 32, 9, 20, 40)]:
+        g = torch.Generator(device=DEV).manual_seed(cin + w)
+        x = torch.randn(n, d, h, w, cin, device=DEV, generator=g).bfloat16()
+        wgt = torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) * 0.1
+        b = torch.randn(cout, device=DEV, generator=g)
+        wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, h, w)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        outs = []
+        for v in ("0", "1"):
+            monkeypatch.setenv("MI3D_CONV8", v)
+            y = torch.empty(n, d, h, w, cout, device=DEV, dtype=torch.bfloat16)
+            call("mi3d_conv3_forward", 1, 1, ptr(x), cin, cin, ptr(wgt), ptr(b), ptr(y), cout, cout, n, d, h, w, ptr(ws), wsb, None)
+            outs.append(y.clone())
+        monkeypatch.delenv("MI3D_CONV8")
+        assert torch.equal(outs[0], outs[1]), (n, cin, cout, d, h, w)
