@@ -1145,8 +1145,11 @@ inline int pick_ksplit(int Cin, int Cout, Geo g, int target_override = 0) {
     if (big_geo(g)) return 1;
     int64_t wgs = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 8) * (Cout / (Cout % 32 == 0 ? 32 : 16));
     int nchunk = Cin / 16, k = 1;
-    static const int target = getenv("MI3D_KS_TARGET") ? atoi(getenv("MI3D_KS_TARGET")) : 256;
-    const int tgt = target_override > 0 ? target_override : target;
+    // split-K workgroup target.  Round 2 (four-wave kernels): 128 / 256 / 512 / 1024 -> 2.375 / 2.350 / 2.395 / 2.421 ms.  Round 3
+    // (eight-wave kernels: a workgroup's chain is half as long, fewer and fatter workgroups win; more layers keep their BatchNorm
+    // partial sums in the conv epilogue): 64 / 96 / 128 / 192 / 256 / 384 / 512 -> 2.252 / 2.229 / 2.219 / 2.221 / 2.263 / 2.265 / 2.286 ms
+    static const int target = getenv("MI3D_KS_TARGET") ? atoi(getenv("MI3D_KS_TARGET")) : 128;
+    const int tgt = target_override > 0 ? (target_override < target ? target_override : target) : target;
     while (wgs * k < tgt && k * 2 <= nchunk && nchunk % (k * 2) == 0 && k < 16) k *= 2;
     return k;
 }
@@ -1214,8 +1217,8 @@ bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g) { return persist_ok(Cin, Cou
 
 int conv3_bwd_ks_target() {
     const char* e_k = getenv("MI3D_KS_TARGET_BWD");
-    int kst = e_k ? atoi(e_k) : 128;
-    return kst > 256 ? 256 : (kst < 1 ? 1 : kst);
+    int kst = e_k ? atoi(e_k) : 128;          // pick_ksplit clamps it to the forward target (the planned split-K scratch)
+    return kst < 1 ? 1 : kst;
 }
 
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
