@@ -72,7 +72,7 @@ def model(rows, net):
             layer, what = "all weights", "pack fp32 -> 2 bf16 MFMA images"
             conv_w = sum(27 * ci * co for _, _, ci, co in net.halves[1:])
             by = conv_w * 4 + 2 * conv_w * 2 * 28 / 27
-        elif phase == "fwd" and ("conv3_c1_fwd" in n or "conv3_mfma_persist" in n or re.match(r"conv3_mfma_kernel", n)):
+        elif phase == "fwd" and ("conv3_c1_fwd" in n or "conv3_mfma_persist" in n or re.match(r"conv3_mfma8?_kernel", n)):
             fi += 1
             name, l, ci, co = net.halves[fi]
             layer, what = name, "conv3 fwd" + (" (split-K partials)" if "false, true>" in n else "")
