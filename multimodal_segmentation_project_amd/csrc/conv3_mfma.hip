@@ -1356,7 +1356,29 @@ __device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restric
     bool do_db = (tg == 0 && bid_.z == 0);
 
     int ntiles = N * tilesZ * tilesY * tilesX;
-    constexpr int NA = (CO_B * WNV * 2 + BLK - 1) / BLK, NB = (CI_B * WNH * 2 + BLK - 1) / BLK;
+    // Staging map, tile-invariant and computed ONCE (round 3: the per-tile div/mod + bounds chains of 13 loads were ~800 vector
+    // instructions per tile against 108 MFMAs -- the kernel was bound by its address arithmetic):
+    //   dy   slot it = z-slice it of the 4x8x16 tile; thread t -> voxel (iy, ix) = ((t >> 1) / 16, (t >> 1) % 16), channel half t & 1
+    //   x    the 6 halo slices as 3 slice pairs; pair p = slices 2p, 2p + 1 = 360 voxels = 3 slots of 120 voxels (threads 0..239)
+    // Per tile only the origin moves: validity in y / x is one compare pair per slot KIND, in z one scalar-ish compare per slot, and
+    // every address is a uniform base + a fixed 32-bit lane offset.  The LDS image ([voxel][16 channels]) is unchanged.
+    static_assert(CO_B == 1 && CI_B == 1 && BLK == 256 && WTY * WTX * 2 == BLK && WIY * WIX * 2 == 360, "staging map");
+    constexpr int NA = WTZ, NXJ = 3, NXP = WIZ / 2, NB = NXP * NXJ;
+    const int hv = threadIdx.x >> 1, hf = threadIdx.x & 1;
+    const int a_iy = hv / WTX, a_ix = hv % WTX;
+    const unsigned a_rel = (unsigned)(((a_iy * W + a_ix) * dycs + hf * 8) * 2);         // bytes from the tile origin
+    const bool b_act = threadIdx.x < 240;
+    int b_iy[NXJ], b_ix[NXJ], b_iz[NXJ];
+    unsigned b_rel[NXJ];
+#pragma unroll
+    for (int j = 0; j < NXJ; j++) {
+        int v = 120 * j + (b_act ? hv : 0);
+        b_iz[j] = v / (WIY * WIX);
+        int r = v % (WIY * WIX);
+        b_iy[j] = r / WIX;
+        b_ix[j] = r % WIX;
+        b_rel[j] = (unsigned)((((b_iz[j] * H + b_iy[j]) * W + b_ix[j]) * xcs + hf * 8) * 2);   // bytes from the halo origin of the pair
+    }
     bf16x8 va[NA], vb[NB];
     auto load_tile = [&](int tile) {
         int t = tile;
@@ -1364,28 +1386,29 @@ __device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restric
         int ty_ = t % tilesY; t /= tilesY;
         int tz_ = t % tilesZ; int n = t / tilesZ;
         int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
-        const bf16* dyn = dy + (int64_t)n * D * H * W * dycs + co0;
-        const bf16* xn = x + (int64_t)n * D * H * W * xcs + ci0 + ((ci0 >> 4) >= xh.split ? xh.delta : 0);
+        const char* dyn = reinterpret_cast<const char*>(dy + ((((int64_t)n * D + z0) * H + y0) * W + x0) * dycs + co0);
+        // halo origin (z0 - 1, y0 - 1, x0 - 1): may lie in front of the sample; only in-range lanes dereference
+        const char* xn = reinterpret_cast<const char*>(x + ci0 + ((ci0 >> 4) >= xh.split ? xh.delta : 0)) +
+                         ((((int64_t)n * D + (z0 - 1)) * H + (y0 - 1)) * W + (x0 - 1)) * xcs * 2;
+        const int64_t a_zs = (int64_t)H * W * dycs * 2, b_zs = (int64_t)H * W * xcs * 2;
+        bool a_ok = y0 + a_iy < H && x0 + a_ix < W;
 #pragma unroll
         for (int it = 0; it < NA; it++) {
-            int idx = threadIdx.x + it * BLK;
-            int half = idx & 1, vox = (idx >> 1) % WNV, cb = (idx >> 1) / WNV;
-            int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
-            int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
             va[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < CO_B * WNV * 2 && gz < D && gy < H && gx < W)
-                va[it] = *reinterpret_cast<const bf16x8*>(dyn + ((gz * H + gy) * W + gx) * dycs + cb * 16 + half * 8);
+            if (a_ok && z0 + it < D) va[it] = *reinterpret_cast<const bf16x8*>(dyn + it * a_zs + a_rel);
         }
+        bool b_ok[NXJ];
 #pragma unroll
-        for (int it = 0; it < NB; it++) {
-            int idx = threadIdx.x + it * BLK;
-            int half = idx & 1, vox = (idx >> 1) % WNH, cb = (idx >> 1) / WNH;
-            int ix = vox % WIX, tt = vox / WIX, iy = tt % WIY, iz = tt / WIY;
-            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
-            vb[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < CI_B * WNH * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                vb[it] = *reinterpret_cast<const bf16x8*>(xn + ((gz * H + gy) * W + gx) * xcs + cb * 16 + half * 8);
-        }
+        for (int j = 0; j < NXJ; j++)
+            b_ok[j] = b_act && (unsigned)(y0 - 1 + b_iy[j]) < (unsigned)H && (unsigned)(x0 - 1 + b_ix[j]) < (unsigned)W;
+#pragma unroll
+        for (int pz = 0; pz < NXP; pz++)
+#pragma unroll
+            for (int j = 0; j < NXJ; j++) {
+                vb[pz * NXJ + j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (b_ok[j] && (unsigned)(z0 - 1 + 2 * pz + b_iz[j]) < (unsigned)D)
+                    vb[pz * NXJ + j] = *reinterpret_cast<const bf16x8*>(xn + 2 * pz * b_zs + b_rel[j]);
+            }
     };
     // prefetch the next tile into registers while computing (only where the register file has room for it)
     constexpr bool PF = (NT * CO_B * CI_B + NA + NB) * 4 <= 300;
@@ -1394,14 +1417,11 @@ __device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restric
         if (!PF) load_tile(tile);
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < NA; it++) {
-            int idx = threadIdx.x + it * BLK;
-            if (idx < CO_B * WNV * 2) *reinterpret_cast<bf16x8*>(dys + idx * 8) = va[it];
-        }
+        for (int it = 0; it < NA; it++) *reinterpret_cast<bf16x8*>(dys + (threadIdx.x + it * BLK) * 8) = va[it];
+        if (b_act) {
 #pragma unroll
-        for (int it = 0; it < NB; it++) {
-            int idx = threadIdx.x + it * BLK;
-            if (idx < CI_B * WNH * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = vb[it];
+            for (int it = 0; it < NB; it++)
+                *reinterpret_cast<bf16x8*>(xs + ((it / NXJ) * 720 + (it % NXJ) * 240 + threadIdx.x) * 8) = vb[it];
         }
         __syncthreads();
         if (PF && tile + nsb < ntiles) load_tile(tile + nsb);     // next tile's loads fly under this tile's MFMAs
@@ -1420,7 +1440,7 @@ __device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restric
         // x fragments are walked by HALO slice zz = z + dz: one fragment (zz, dy, dx, ci-block) feeds the up to three
         // (z, dz) pairs with z + dz = zz  ->  6*9 instead of 4*27 transposed LDS reads per ci-block (2x fewer).
         // They stream through a PFD-deep register ring (2*PFD tr-reads in flight ahead of the MFMAs).
-        constexpr int NB = WIZ * NY * 3 * CI_B, PFD = 4;
+        constexpr int NBF = WIZ * NY * 3 * CI_B, PFD = 4;
         auto bfrag = [&](int t) {
             int b_ = t % CI_B, r = t / CI_B;
             int dx = r % 3; r /= 3;
@@ -1432,9 +1452,9 @@ __device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restric
 #pragma unroll
         for (int t = 0; t < PFD; t++) Bq[t] = bfrag(t);
 #pragma unroll
-        for (int t = 0; t < NB; t++) {
+        for (int t = 0; t < NBF; t++) {
             bf16x8 Bc = Bq[t % PFD];
-            if (t + PFD < NB) Bq[t % PFD] = bfrag(t + PFD);
+            if (t + PFD < NBF) Bq[t % PFD] = bfrag(t + PFD);
             int b_ = t % CI_B, r = t / CI_B;
             int dx = r % 3; r /= 3;
             int dyi = r % NY, zz = r / NY;
