@@ -148,6 +148,32 @@ int mi3d_seg_loss_backward(const float* logits, const int64_t* labels, const flo
 int mi3d_seg_loss_metrics_forward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int D,
                                   int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out,
                                   void* loss_workspace, void* metrics_workspace, void* stream);
+/* The training step (train_unet.py:224-232, train_dann.py:268-281) uses the logits only inside the loss, so the 1x1x1 head
+ * (models/unet.py:62,87) and the loss can be one pass each way and neither logits nor dlogits ever reach memory:
+ *   mi3d_unet_forward_loss  = mi3d_unet_forward + mi3d_seg_loss_metrics_forward   (logits_opt: NULL, or where to keep them)
+ *   mi3d_unet_backward_loss = mi3d_seg_loss_backward + mi3d_unet_backward         (grad_scale: device float[1] or NULL = 1)
+ * Every logit has the bits of the unfused head; the forward sums add the voxels in another order (loss equal to a few ulp,
+ * the integer counts behind the metrics exactly), the backward is bit-identical to the unfused pair given the same `coef`.
+ * mi3d_unet_head_loss_supported: 1 if the configuration has the fused kernels (bf16 activations, features[0] == 16,
+ * <= 4 classes, no distillation term), else 0 and the two calls fail with MI3D_EINVAL. */
+int mi3d_unet_head_loss_supported(const mi3d_unet_desc* d, const mi3d_loss_cfg* cfg);
+/* The two fused passes as operators (z: the decoder output, channels-last bf16 (N,V,zcs); w (C,Cin), bias (C) float;
+ * workspace of mi3d_head_loss_backward: mi3d_conv1_workspace_bytes(Cin, C)). */
+int mi3d_head_loss_supported(int dtype, int Cin, int C, const mi3d_loss_cfg* cfg);
+int mi3d_head_loss_forward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
+                           int D, int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out,
+                           void* loss_workspace, void* metrics_workspace, float* logits_opt, void* stream);
+int mi3d_head_loss_backward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
+                            int64_t V, const mi3d_loss_cfg* cfg, const float* coef, const float* grad_scale, void* dz, int dzcs,
+                            float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int mi3d_unet_forward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
+                           const float* drop_scales, int training, const int64_t* labels, const mi3d_loss_cfg* cfg,
+                           float* loss_out, float* coef, float* metrics_out, void* loss_workspace, void* metrics_workspace,
+                           float* logits_opt, float* gap_out, void* workspace, size_t workspace_bytes, void* stream);
+int mi3d_unet_backward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
+                            const float* drop_scales, const int64_t* labels, const mi3d_loss_cfg* cfg, const float* coef,
+                            const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin, int seg_end,
+                            void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events);
 size_t mi3d_seg_metrics_workspace_bytes(int C);
 /* out: device float[3] = {iou, dice, accuracy}; D = first spatial dim (reference loop bound, metrics.py:74,101) */
 int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,

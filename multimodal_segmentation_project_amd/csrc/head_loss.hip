@@ -504,6 +504,29 @@ __global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* _
     seg_loss_finalize_body(part, nblk, N, C, V, cfg, loss_out, coef);
 }
 
+// dL/dz of one voxel (header of this file); shared by the plain backward pass and the head-fused one so that both
+// produce the same bits from the same logits
+template <int NC>
+__device__ __forceinline__ void dlogits_voxel(const float (&z)[NC], int t, int C, const float (&A)[NC], const float (&B)[NC],
+                                              float ce_s, float go, const float (&kd)[NC], float (&o)[NC]) {
+    // no implicit contraction in here: which multiply fuses with which add would otherwise depend on the kernel this is inlined
+    // into (measured: one ulp between the two callers at C = 3); the fused multiply-adds are written out
+#pragma clang fp contract(off)
+    float p[NC], g[NC], lse;
+    softmax_c<NC>(z, C, 1.f, p, lse);
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        g[c] = (c == t ? A[c] : 0.f) + B[c];
+        dot = fmaf(g[c], p[c], dot);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        float u = p[c] * (g[c] - dot) + kd[c];
+        o[c] = go * fmaf(ce_s, p[c] - (c == t ? 1.f : 0.f), u);
+    }
+}
+
 template <int NC, int VV, bool EXACT, bool TEACH>
 __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                            const float* __restrict__ teacher, int C_, int64_t V,
@@ -531,14 +554,6 @@ __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restri
         if constexpr (TEACH) load_planes<NC, VV>(tg, C, V, v0, zt_);
 #pragma unroll
         for (int k = 0; k < VV; k++) {
-            float p[NC], g[NC], lse;
-            softmax_c<NC>(z[k], C, 1.f, p, lse);
-            float dot = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                g[c] = (c == t[k] ? A[c] : 0.f) + B[c];
-                dot += g[c] * p[c];
-            }
             float kd[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) kd[c] = 0.f;
@@ -549,8 +564,7 @@ __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restri
 #pragma unroll
                 for (int c = 0; c < NC; c++) kd[c] = kd_s * (ps[c] - pt[c]);
             }
-#pragma unroll
-            for (int c = 0; c < NC; c++) o[k][c] = go * (ce_s * (p[c] - (c == t[k] ? 1.f : 0.f)) + p[c] * (g[c] - dot) + kd[c]);
+            dlogits_voxel<NC>(z[k], t[k], C, A, B, ce_s, go, kd, o[k]);
         }
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -558,6 +572,284 @@ __global__ __launch_bounds__(BLK) void seg_loss_bwd_kernel(const float* __restri
                 if constexpr (VV == 4) *reinterpret_cast<float4*>(dg + (int64_t)c * V + v0) = float4{o[0][c], o[1][c], o[2][c], o[3][c]};
                 else dg[(int64_t)c * V + v0] = o[0][c];
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- head + loss in one pass (training step)
+// The training step needs the logits only inside the loss: logits = head(z) feed seg_loss_fwd (+ metrics) and, recomputed from
+// the same z, seg_loss_bwd -> conv1_bwd.  Unfused that is logits written once and read twice and dlogits written and read once
+// (5 x 28 MB at 96^3 N=2) and two more launches; fused, neither tensor exists.  The head is evaluated with conv1_fwd_kernel's
+// exact expression (bias, then fmaf over ci in order), so every logit has the bits of the unfused path; the forward sums differ
+// from seg_loss_fwd_kernel's only in the order the voxels are added (one voxel per thread here: consecutive lanes read
+// consecutive 32-byte channel rows), the backward is bit-identical to seg_loss_bwd + conv1_bwd_mfma given the same `coef`.
+template <int NC>
+__device__ __forceinline__ void head_logits16(const bf16* __restrict__ zrow, int Cin, const float* __restrict__ w,
+                                              const float* __restrict__ bias, int C, float (&z)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) z[c] = (bias && c < C) ? bias[c] : 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += CINB) {
+        float zv[CINB];
+        load_cin_block<bf16, true>(zrow + c0, CINB, zv);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < CINB; i++) z[c] = fmaf(zv[i], w[(int64_t)c * Cin + c0 + i], z[c]);
+            }
+        }
+    }
+}
+
+// HLW waves per workgroup: the partial rows (one per workgroup) are capped at LOSS_MAXBLK for the single-workgroup finalize, so the
+// waves a streaming pass needs to cover the memory latency come from fat workgroups (1024 threads: 32 waves per CU at 2 per CU)
+constexpr int HLW = 16;
+template <int NC, bool METRICS, bool EXACT>
+__global__ __launch_bounds__(HLW * 64) void head_loss_fwd_kernel(const bf16* __restrict__ zin, int zcs, int Cin, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const int64_t* __restrict__ labels,
+                                                            int C_, int64_t V, double* __restrict__ part,
+                                                            unsigned long long* __restrict__ counts, float* __restrict__ logits_opt) {
+    const int C = EXACT ? NC : C_;
+    constexpr int NQL = 2 + 3 * NC;
+    __shared__ float red[HLW][NQL];
+    __shared__ unsigned redc[HLW][3 * NC + 1];
+    unsigned ni[NC], np[NC], nt[NC];                 // wave-uniform (scalar registers)
+#pragma unroll
+    for (int c = 0; c < NC; c++) ni[c] = np[c] = nt[c] = 0;
+    int n = blockIdx.y;
+    const bf16* zn = zin + (int64_t)n * V * zcs;
+    const int64_t* lb = labels + (int64_t)n * V;
+    float q[2 + 2 * NC];                             // ce, (kl = 0), I[c], P[c]
+#pragma unroll
+    for (int i = 0; i < 2 + 2 * NC; i++) q[i] = 0.f;
+    // every wave runs the same number of iterations (the ballots below are wave-wide): out-of-range lanes carry t = -1.
+    // Two 64-voxel groups per iteration, loads of both issued first (a wave has only ~3 iterations: latency, not issue, bounds it)
+    constexpr int U = 2;
+    const int64_t gstride = (int64_t)gridDim.x * (HLW * 64);
+    int64_t base = (int64_t)blockIdx.x * (HLW * 64) + (threadIdx.x & ~63);
+    for (; base < V; base += U * gstride) {
+        bf16x8 zr[U][2];
+        int tt[U];
+        bool lv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int64_t v = base + u * gstride + (threadIdx.x & 63);
+            lv[u] = v < V;
+            tt[u] = -1;
+            zr[u][0] = zr[u][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (lv[u]) {
+                static_assert(CINB == 16, "one 32-byte row");
+                zr[u][0] = *reinterpret_cast<const bf16x8*>(zn + v * zcs);
+                zr[u][1] = *reinterpret_cast<const bf16x8*>(zn + v * zcs + 8);
+                tt[u] = (int)lb[v];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (base + u * gstride >= V) break;                       // wave-uniform
+            int64_t v = base + u * gstride + (threadIdx.x & 63);
+            bool live = lv[u];
+            float z[NC];
+            int t = tt[u];
+            if (Cin == CINB) {
+                __attribute__((aligned(16))) bf16 row[16];
+                *reinterpret_cast<bf16x8*>(row) = zr[u][0];
+                *reinterpret_cast<bf16x8*>(row + 8) = zr[u][1];
+                head_logits16<NC>(row, CINB, w, bias, C, z);
+            } else if (live) head_logits16<NC>(zn + v * zcs, Cin, w, bias, C, z);
+            if (live) {
+                if (logits_opt) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                        if (EXACT || c < C) logits_opt[((int64_t)n * C + c) * V + v] = z[c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; c++) z[c] = 0.f;
+            }
+            float p[NC], lse;
+            softmax_c<NC>(z, C, 1.f, p, lse);
+            float zt = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (EXACT || c < C) {
+                    bool is = (c == t);
+                    zt = is ? z[c] : zt;
+                    q[2 + c] += is ? p[c] : 0.f;
+                    q[2 + NC + c] += live ? p[c] : 0.f;
+                }
+            }
+            q[0] += live ? lse - zt : 0.f;
+            float bvv = z[0];
+            int best = 0;
+#pragma unroll
+            for (int c = 1; c < NC; c++)
+                if ((EXACT || c < C) && z[c] > bvv) { bvv = z[c]; best = c; }
+            if (!live) best = -1;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                unsigned long long mt = __ballot(t == c);
+                nt[c] += (unsigned)__popcll(mt);
+                if constexpr (METRICS) {
+                    unsigned long long mb = __ballot(best == c);
+                    np[c] += (unsigned)__popcll(mb);
+                    ni[c] += (unsigned)__popcll(mb & mt);
+                }
+            }
+        }
+    }
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 2 + 2 * NC; i++) {
+        float sv = wave_sum(q[i]);
+        if (lane == 0) red[wave][i] = sv;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            red[wave][2 + 2 * NC + c] = (float)nt[c];
+            redc[wave][c] = ni[c]; redc[wave][NC + c] = np[c]; redc[wave][2 * NC + c] = nt[c];
+        }
+    }
+    __syncthreads();
+    const int nqc = 2 + 3 * C;                        // the compact rows of seg_loss_fwd_kernel: same finalize kernels
+    if ((int)threadIdx.x < nqc) {
+        int i = threadIdx.x, src = i;
+        if (i >= 2) { int k = (i - 2) / C, c = (i - 2) % C; src = 2 + k * NC + c; }
+        double v = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < HLW; wv++) v += (double)red[wv][src];
+        part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * nqc + i] = v;
+    }
+    if constexpr (METRICS) {
+        if ((int)threadIdx.x < 3 * C + 1) {
+            int i = threadIdx.x;
+            unsigned long long v = 0;
+            if (i < 3 * C) {
+                int src = (i / C) * NC + (i % C);
+                for (int wv = 0; wv < HLW; wv++) v += redc[wv][src];
+            } else {
+                for (int wv = 0; wv < HLW; wv++)
+#pragma unroll
+                    for (int c = 0; c < NC; c++) v += redc[wv][c];
+            }
+            counts[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (3 * C + 1) + i] = v;
+        }
+    }
+}
+
+// conv1_bwd_mfma_kernel with dlogits made on the spot: the wave stages its 32 x 16 z tile as before, lanes l and l + 32
+// re-derive voxel l's logits from that tile (head_logits16: the forward's bits), turn them into dL/dz with dlogits_voxel and
+// leave them in a wave-private [class][32 voxels] LDS tile, from which both MFMA operands are read where the plain kernel
+// reads the dlogits planes.  Cin = 16 (one input block), Cout <= 4.
+__global__ __launch_bounds__(C1W * 64) void head_loss_bwd_mfma_kernel(const bf16* __restrict__ z, int zcs, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias, const int64_t* __restrict__ labels,
+                                                                      int Cout, const float* __restrict__ coef,
+                                                                      const float* __restrict__ grad_out, bf16* __restrict__ dz, int dzcs,
+                                                                      int64_t V, float* __restrict__ slabs) {
+    constexpr int NC = 4, Cin = 16;
+    __shared__ __attribute__((aligned(16))) bf16 zt[C1W][2][32 * 16];
+    __shared__ __attribute__((aligned(16))) float dlt[C1W][2][NC * 32];
+    __shared__ float red[C1W][64][4];
+    __shared__ float redb[C1W][16];
+    int n = blockIdx.y;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int vn = lane & 15, kg = lane >> 4;
+    const bf16* zn = z + (int64_t)n * V * zcs;
+    bf16* dzn = dz ? dz + (int64_t)n * V * dzcs : nullptr;
+    const int64_t* lb = labels + (int64_t)n * V;
+    float go = grad_out ? grad_out[0] : 1.f;
+    float A[NC], B[NC], kd0[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { A[c] = coef[c]; B[c] = coef[MAXC + c]; kd0[c] = 0.f; }
+    float ce_s = coef[2 * MAXC];
+    bf16x8 aw;
+#pragma unroll
+    for (int j = 0; j < 8; j++) aw[j] = (bf16)0.f;
+    aw[0] = (bf16)(kg < Cout ? w[(int64_t)kg * Cin + vn] : 0.f);
+    f32x4 accW = {0.f, 0.f, 0.f, 0.f};
+    float dbs = 0.f;
+    int laneK = ((8 * kg + ((lane & 15) >> 2)) * 16 + 4 * (lane & 3)) * 2;
+    // the wave's 32-voxel chunks are those of conv1_bwd_mfma_kernel, in its order, but taken two at a time: lanes 0-31 make the
+    // dlogits of chunk k, lanes 32-63 those of chunk k + 1 (64 distinct voxels per pass of the per-voxel arithmetic); a chunk
+    // beyond V is all zeros and adds nothing
+    const int64_t stride = (int64_t)gridDim.x * (C1W * 32);
+    for (int64_t v0 = ((int64_t)blockIdx.x * C1W + wave) * 32; v0 < V; v0 += 2 * stride) {
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            int64_t v = v0 + hh * stride + (lane >> 1);
+            bf16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (v < V) t = *reinterpret_cast<const bf16x8*>(zn + v * zcs + (lane & 1) * 8);
+            *reinterpret_cast<bf16x8*>(zt[wave][hh] + (lane >> 1) * 16 + (lane & 1) * 8) = t;
+        }
+        const int hl = lane >> 5;
+        int64_t vl = v0 + hl * stride + (lane & 31);
+        int tl = vl < V ? (int)lb[vl] : 0;
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the tiles are private to this wave
+        __builtin_amdgcn_wave_barrier();
+        {
+            float zl[NC], o[NC];
+            head_logits16<NC>(zt[wave][hl] + (lane & 31) * 16, Cin, w, bias, Cout, zl);
+            dlogits_voxel<NC>(zl, tl, Cout, A, B, ce_s, go, kd0, o);
+#pragma unroll
+            for (int c = 0; c < NC; c++) dlt[wave][hl][c * 32 + (lane & 31)] = (c < Cout && vl < V) ? o[c] : 0.f;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int64_t vc = v0 + hh * stride;
+            // dW: B = dl, 8 consecutive voxels of class vn
+            bf16x8 bd = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (vn < Cout) {
+                float4 p4 = *reinterpret_cast<const float4*>(&dlt[wave][hh][vn * 32 + 8 * kg]), q4 = *reinterpret_cast<const float4*>(&dlt[wave][hh][vn * 32 + 8 * kg + 4]);
+                float t8[8] = {p4.x, p4.y, p4.z, p4.w, q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) { bd[j] = (bf16)t8[j]; dbs += t8[j]; }
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; nb++) {
+                int64_t v = vc + nb * 16 + vn;
+                bf16x8 bl = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (v < V && kg < Cout) bl[0] = (bf16)dlt[wave][hh][kg * 32 + nb * 16 + vn];
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, bl, o, 0, 0, 0);
+                if (dzn && v < V) {
+                    bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                    *reinterpret_cast<bf16x4*>(dzn + v * dzcs + 4 * kg) = ob;
+                }
+            }
+            bf16x8 az = tr_frag_h(reinterpret_cast<const char*>(zt[wave][hh]), laneK);
+            accW = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az, bd, accW, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    *reinterpret_cast<f32x4*>(&red[wave][lane][0]) = accW;
+    float sb = dbs;
+    sb += __shfl_xor(sb, 16, 64);
+    sb += __shfl_xor(sb, 32, 64);
+    if (lane < 16) redb[wave][lane] = sb;
+    __syncthreads();
+    int64_t nW = (int64_t)Cout * Cin;
+    float* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (nW + Cout);
+    if (threadIdx.x < 64) {
+        int l = threadIdx.x, co = l & 15, g4 = l >> 4;
+        if (co < Cout) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float sv = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < C1W; wv++) sv += red[wv][l][r];
+                slab[(int64_t)co * Cin + 4 * g4 + r] = sv;
+            }
+        }
+    } else if (threadIdx.x < 64 + 16) {
+        int co = threadIdx.x - 64;
+        if (co < Cout) {
+            float sv = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < C1W; wv++) sv += redb[wv][co];
+            slab[nW + co] = sv;
         }
     }
 }
@@ -834,4 +1126,55 @@ int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D,
     if (counts_out) seg_counts_finalize_kernel<<<1, 1024, 0, s>>>((const unsigned long long*)ws, bx * N, C, (long long*)counts_out);
     MI3D_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- head + loss fused (training step)
+bool head_loss_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg) {
+    return dtype == MI3D_BF16 && Cin % CINB == 0 && zcs % 8 == 0 && al16(z) && C >= 1 && C <= 4 && cfg.w_kd == 0.f &&
+           !getenv("MI3D_NO_HEAD_LOSS");
+}
+bool head_loss_bwd_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg, const void* dz, int dzcs) {
+    return head_loss_ok(dtype, z, zcs, Cin, C, cfg) && Cin == 16 && (!dz || (dzcs % 4 == 0 && ((uintptr_t)dz % 8) == 0)) &&
+           !getenv("MI3D_NO_CONV1_MFMA");
+}
+
+int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
+                  int64_t V, LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s, int D, float* metrics_out,
+                  void* metrics_ws, float* logits_opt) {
+    MI3D_CHECK_ARG(head_loss_ok(MI3D_BF16, z, zcs, Cin, C, cfg), "head_loss_fwd: unsupported shape Cin=%d C=%d", Cin, C);
+    MI3D_CHECK_ARG(N <= LOSS_MAXBLK, "head_loss_fwd: batch %d > %d unsupported", N, LOSS_MAXBLK);
+    int64_t wantb = (V + HLW * 64 - 1) / (HLW * 64), capb = LOSS_MAXBLK / N < 1 ? 1 : LOSS_MAXBLK / N;
+    int bx = (int)(wantb < capb ? wantb : capb);
+    dim3 grid((unsigned)bx, (unsigned)N);
+    bool met = metrics_out && metrics_ws;
+    unsigned long long* cw = (unsigned long long*)metrics_ws;
+    const bf16* zp = (const bf16*)z;
+#define HLF(ME_, EX_) head_loss_fwd_kernel<4, ME_, EX_><<<grid, HLW * 64, 0, s>>>(zp, zcs, Cin, w, bias, labels, C, V, (double*)ws, cw, logits_opt)
+    if (met && C == 4) HLF(true, true);
+    else if (met) HLF(true, false);
+    else if (C == 4) HLF(false, true);
+    else HLF(false, false);
+#undef HLF
+    MI3D_LAUNCH_CHECK();
+    if (met) seg_loss_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, cw, bx * N, N, C, D, V, cfg, loss_out, coef, metrics_out);
+    else seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, bx * N, N, C, V, cfg, loss_out, coef);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
+int head_loss_bwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int C,
+                  LossCfg cfg, const float* coef, const float* grad_out, void* dz, int dzcs, float* dW, float* db, int accumulate,
+                  float* ws, int N, int64_t V, hipStream_t s, SlabJob* pend) {
+    MI3D_CHECK_ARG(head_loss_bwd_ok(MI3D_BF16, z, zcs, Cin, C, cfg, dz, dzcs), "head_loss_bwd: unsupported shape Cin=%d C=%d", Cin, C);
+    MI3D_CHECK_ARG(N <= CONV1_NBLK, "head_loss_bwd: batch %d > %d unsupported", N, CONV1_NBLK);
+    int64_t nW = (int64_t)Cin * C;
+    const int capb = 1024;             // as conv1_bwd's matrix-core route: same workgroup -> voxel map, same slabs
+    int64_t want = (V + C1W * 32 - 1) / (C1W * 32);
+    int bx = capb / N < 1 ? 1 : capb / N;
+    if (bx > want) bx = (int)want;
+    dim3 grid((unsigned)bx, (unsigned)N, 1);
+    head_loss_bwd_mfma_kernel<<<grid, C1W * 64, 0, s>>>((const bf16*)z, zcs, w, bias, labels, C, coef, grad_out, (bf16*)dz, dzcs, V, ws);
+    MI3D_LAUNCH_CHECK();
+    if (pend) { *pend = slab_job_make(0, ws, bx * N, nW + C, nW, dW, db, Cin, C, accumulate); return 0; }
+    return slab_reduce(ws, bx * N, nW + C, nW, dW, db, accumulate, s);
 }

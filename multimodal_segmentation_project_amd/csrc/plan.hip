@@ -464,12 +464,26 @@ int mi3d_unet_segment_params(const mi3d_unet_desc* d, int seg, int* r) {
     return 0;
 }
 
-int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
+}  // extern "C"
+
+// the segmentation loss of the training loop folded into the 1x1x1 head (head_loss.hip): forward half / backward half
+struct HeadLoss {
+    const int64_t* labels; LossCfg cfg; float* loss_out; float* coef; float* metrics_out; void* loss_ws; void* met_ws;   // forward
+    const float* grad_scale;                                                                                              // backward
+};
+static LossCfg cfg_of(const mi3d_loss_cfg* c) {
+    LossCfg k;
+    k.w_ce = c->w_ce; k.region_kind = c->region_kind; k.w_reg = c->w_reg; k.alpha = c->alpha; k.beta = c->beta; k.eps = c->eps;
+    k.w_kd = c->w_kd; k.temp = c->temperature > 0.f ? c->temperature : 1.f;
+    return k;
+}
+
+static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
                       const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+                      size_t workspace_bytes, void* stream, const HeadLoss* hl) {
     Plan p;
     MI3D_TRY(build_plan(d, p));
-    MI3D_CHECK_ARG(x && params && logits && workspace, "mi3d_unet_forward: null pointer");
+    MI3D_CHECK_ARG(x && params && (logits || hl) && workspace, "mi3d_unet_forward: null pointer");
     MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
     MI3D_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
@@ -520,9 +534,42 @@ int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const
             MI3D_TRY(nearest_resize_fwd(p.dt, udst, udcs, p.C[l], p.up_geo(l), catl + p.half_off(l), p.catcs(l), p.geo[l], c.s));
         MI3D_TRY(block_forward(c, L + 1 + i, x, buffers, drop_scales, training));
     }
+    if (hl) {
+        MI3D_CHECK_ARG(head_loss_ok(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], d->out_channels, hl->cfg),
+                       "mi3d_unet_forward_loss: no fused head + loss for this configuration (see mi3d_unet_head_loss_supported)");
+        return head_loss_fwd(c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), hl->labels, d->N,
+                             d->out_channels, p.geo[0].V(), hl->cfg, hl->loss_out, hl->coef, hl->loss_ws, c.s, d->D, hl->metrics_out,
+                             hl->met_ws, logits);
+    }
     MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
                        d->out_channels, d->N, p.geo[0].V(), c.s));
     return 0;
+}
+
+extern "C" {
+
+int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
+                      const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    MI3D_CHECK_ARG(logits, "mi3d_unet_forward: null pointer");
+    return unet_forward_impl(d, x, params, buffers, drop_scales, training, logits, gap_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+int mi3d_unet_head_loss_supported(const mi3d_unet_desc* d, const mi3d_loss_cfg* cfg) {
+    Plan p;
+    if (!d || !cfg || build_plan(d, p) != 0) return 0;
+    LossCfg k = cfg_of(cfg);
+    // the plan's activations are 256-byte aligned and dense: only dtype / channel counts / loss terms decide
+    return head_loss_bwd_ok(p.dt, nullptr, p.C[0], p.C[0], d->out_channels, k, nullptr, p.C[0]) ? 1 : 0;
+}
+
+int mi3d_unet_forward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
+                           const float* drop_scales, int training, const int64_t* labels, const mi3d_loss_cfg* cfg,
+                           float* loss_out, float* coef, float* metrics_out, void* loss_workspace, void* metrics_workspace,
+                           float* logits_opt, float* gap_out, void* workspace, size_t workspace_bytes, void* stream) {
+    MI3D_CHECK_ARG(labels && cfg && loss_out && coef && loss_workspace, "mi3d_unet_forward_loss: null pointer");
+    HeadLoss hl{labels, cfg_of(cfg), loss_out, coef, metrics_out, loss_workspace, metrics_workspace, nullptr};
+    return unet_forward_impl(d, x, params, buffers, drop_scales, training, logits_opt, gap_out, workspace, workspace_bytes, stream, &hl);
 }
 
 int mi3d_unet_bn_apply_deferred(const mi3d_unet_desc* d, void* const* buffers, const void* const* side, void* stream) {
@@ -604,14 +651,18 @@ int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* 
     return 0;
 }
 
-int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
-                       const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale, int accumulate,
+}  // extern "C"
+
+static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
+                       const float* drop_scales, const float* dlogits_in, const float* dgap, float gap_scale, int accumulate,
                        int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
-                       void* const* events) {
+                       void* const* events, const HeadLoss* hl) {
     Plan p;
     MI3D_TRY(build_plan(d, p));
     MI3D_CHECK_ARG(x && params && grads && workspace, "mi3d_unet_backward: null pointer");
     MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
+    // `dlogits` below only says "the segmentation branch has a gradient": with the fused head it is never dereferenced
+    const float* dlogits = hl ? reinterpret_cast<const float*>(hl->coef) : dlogits_in;
     MI3D_CHECK_ARG(dlogits || dgap, "mi3d_unet_backward: neither dlogits nor dgap given");
     int L = p.L, nseg = 2 * L + 2;
     MI3D_CHECK_ARG(seg_begin >= 0 && seg_end <= nseg && seg_begin <= seg_end, "bad segment range [%d,%d)", seg_begin, seg_end);
@@ -624,9 +675,16 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
         if (seg == 0) {
             if (!dlogits) continue;
             SlabJob* ps = c.pend_slot();
-            MI3D_TRY(conv1_bwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), dlogits, d->out_channels,
-                               c.at(p.gz[0]), p.C[0], G(p.final_pidx()), G(p.final_pidx() + 1), accumulate, wgws, d->N,
-                               p.geo[0].V(), c.s, ps));
+            if (hl) {
+                MI3D_CHECK_ARG(head_loss_bwd_ok(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], d->out_channels, hl->cfg, c.at(p.gz[0]), p.C[0]),
+                               "mi3d_unet_backward_loss: no fused head + loss for this configuration (see mi3d_unet_head_loss_supported)");
+                MI3D_TRY(head_loss_bwd(c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), hl->labels,
+                                       d->out_channels, hl->cfg, hl->coef, hl->grad_scale, c.at(p.gz[0]), p.C[0], G(p.final_pidx()),
+                                       G(p.final_pidx() + 1), accumulate, wgws, d->N, p.geo[0].V(), c.s, ps));
+            } else
+                MI3D_TRY(conv1_bwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), dlogits, d->out_channels,
+                                   c.at(p.gz[0]), p.C[0], G(p.final_pidx()), G(p.final_pidx() + 1), accumulate, wgws, d->N,
+                                   p.geo[0].V(), c.s, ps));
             c.pend_filled();
         } else if (seg <= L) {
             if (!dlogits) continue;
@@ -669,6 +727,26 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
     for (int i = 0; i < 2; i++)
         if (c.rec[i]) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + i], 0));
     return 0;
+}
+
+extern "C" {
+
+int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
+                       const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale, int accumulate,
+                       int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
+                       void* const* events) {
+    return unet_backward_impl(d, x, params, grads, drop_scales, dlogits, dgap, gap_scale, accumulate, seg_begin, seg_end, workspace,
+                              workspace_bytes, stream, aux_stream, events, nullptr);
+}
+
+int mi3d_unet_backward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
+                            const float* drop_scales, const int64_t* labels, const mi3d_loss_cfg* cfg, const float* coef,
+                            const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin, int seg_end,
+                            void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events) {
+    MI3D_CHECK_ARG(labels && cfg && coef, "mi3d_unet_backward_loss: null pointer");
+    HeadLoss hl{labels, cfg_of(cfg), nullptr, const_cast<float*>(coef), nullptr, nullptr, nullptr, grad_scale};
+    return unet_backward_impl(d, x, params, grads, drop_scales, nullptr, dgap, gap_scale, accumulate, seg_begin, seg_end, workspace,
+                              workspace_bytes, stream, aux_stream, events, &hl);
 }
 
 }  // extern "C"

@@ -299,8 +299,10 @@ class TrainStep(_StepBase):
     def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
                  grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
                  compute_dtype=None, use_graph=False, two_stream=False, reference_zero_grad_quirk=False,
-                 force_comm=False, overlap_teacher=True):
-        """reference_zero_grad_quirk: train_unet.py:222 / finetune_ct.py:161 call optimizer.zero_grad() INSIDE
+                 force_comm=False, overlap_teacher=True, keep_logits=False):
+        """keep_logits: the step folds the 1x1x1 head into the loss and never writes the logits (mi3d_unet_forward_loss); True
+        keeps a copy in the static buffer `logits` for callers that read them after step().
+        reference_zero_grad_quirk: train_unet.py:222 / finetune_ct.py:161 call optimizer.zero_grad() INSIDE
         accelerator.accumulate(), where accelerate only really zeroes on the boundary micro-step -> the gradient the
         reference applies is grad(last micro-batch)/accum.  False (default): accumulate all micro-batches
         (what distill_unet.py:114-115 does and what the flag's name promises); True: reproduce the reference's
@@ -311,6 +313,7 @@ class TrainStep(_StepBase):
         self.teacher = kd_teacher
         self.loss_kind = loss
         self.cfg = cfg
+        self.keep_logits = bool(keep_logits)
         # evaluate(): train_unet.py:259-305 uses the training loss_fn; distill_unet.py:149 uses combined_loss
         self.eval_cfg = _loss_cfg("combined" if kd_teacher is not None else loss)
         self.quirk = bool(reference_zero_grad_quirk) and kd_teacher is None
@@ -403,6 +406,8 @@ class TrainStep(_StepBase):
         st["btab"] = ptr_table([b.data_ptr() for b in self.model.buffers()])
         if mode == "train":
             st["dlogits"] = torch.empty_like(st["logits"])
+            st["fused_head"] = (self.teacher is None and not os.environ.get("MI3D_NO_HEAD_LOSS") and
+                                lib.mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.cfg)) == 1)
             st["ndrop"] = lib.mi3d_unet_dropout_count(C.byref(desc))
             st["drop"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
             st["gtab"] = ptr_table([gp if t else None for gp, t in zip(self.arena.grad_ptrs(), trainable)])
@@ -468,8 +473,16 @@ class TrainStep(_StepBase):
             with torch.cuda.stream(ks):
                 call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"],
                      ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], ks.cuda_stream)
-        call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1,
-             ptr(st["logits"]), None, ptr(st["ws"]), st["ws_bytes"], s)
+        n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
+        fused = st["fused_head"]
+        if fused:
+            # 1x1x1 head + loss + metrics in one pass: the logits are never written (mi3d.h, mi3d_unet_forward_loss)
+            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1, ptr(st["y"]),
+                 C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
+                 ptr(st["met_ws"]), ptr(st["logits"]) if self.keep_logits else None, None, ptr(st["ws"]), st["ws_bytes"], s)
+        else:
+            call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1,
+                 ptr(st["logits"]), None, ptr(st["ws"]), st["ws_bytes"], s)
         if self.teacher is not None:
             if self.kd_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.kd_stream)
@@ -478,19 +491,20 @@ class TrainStep(_StepBase):
                 call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"],
                      ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], s)
             t_logits = st["t_logits"]
-        n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
         # loss + metrics (SURVEY Q1 loop bound D) of the same logits in one pass (replaces 3 argmaxes + 2(D-1) host syncs)
-        call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, desc.D, v,
-             C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
-             ptr(st["met_ws"]), s)
+        if not fused:
+            call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, desc.D, v,
+                 C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
+                 ptr(st["met_ws"]), s)
         # the four scalar gathers fused into one 4-float all-reduce; it rides on the first gradient exchange
         # point (one fork of the comm stream less) and is in flight under the rest of the backward
         met = st["metrics"]
         met_pending = self.do_comm
         joined = False
         if run_backward:
-            call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
-                 ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
+            if not fused:
+                call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
+                     ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
             nseg = st["nseg_run"]
             do_comm = self.do_comm and boundary
             aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
@@ -507,9 +521,14 @@ class TrainStep(_StepBase):
                 if last or exch:
                     if budget and in_flight:
                         call("mi3d_set_cu_budget", budget)
-                    call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
-                         ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
-                         self._events)
+                    if fused:
+                        call("mi3d_unet_backward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
+                             ptr(st["y"]), C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), None, 1.0, accumulate, start,
+                             seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux, self._events)
+                    else:
+                        call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
+                             ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
+                             self._events)
                     if budget and in_flight:
                         call("mi3d_set_cu_budget", 0)
                     in_flight = in_flight or bool(exch)
@@ -673,6 +692,8 @@ class DannStep(_StepBase):
         st["logits"] = torch.empty((n, c, desc.D, desc.H, desc.W), dtype=torch.float32, device=dev)
         st["logits_t"] = torch.empty_like(st["logits"])
         st["dlogits"] = torch.empty_like(st["logits"])
+        st["fused_head"] = (not os.environ.get("MI3D_NO_HEAD_LOSS") and
+                            lib.mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.cfg)) == 1)
         st["coef"] = torch.empty(_lib.LOSS_COEF_FLOATS, dtype=torch.float32, device=dev)
         st["loss_ws"] = torch.empty(lib.mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=dev)
         st["met_ws"] = torch.empty(lib.mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=dev)
@@ -737,19 +758,26 @@ class DannStep(_StepBase):
             with torch.cuda.stream(fs):
                 call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab_side"], ptr(drop_t), 2,
                      ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], fs.cuda_stream)
-        call("mi3d_unet_forward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1,
-             ptr(st["logits"]), feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
+        fused = st["fused_head"]
+        if fused:       # source head + loss + metrics in one pass, logits never written (mi3d_unet_forward_loss)
+            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1, ptr(st["y"]),
+                 C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
+                 ptr(st["met_ws"]), None, feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
+        else:
+            call("mi3d_unet_forward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1,
+                 ptr(st["logits"]), feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
         if fs is not None:
             torch.cuda.current_stream().wait_stream(fs)
             call("mi3d_unet_bn_apply_deferred", C.byref(desc), st["btab"], st["btab_side"], s)
         else:
             call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab"], ptr(drop_t), 1,
                  ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], s)
-        call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
-             C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
-             ptr(st["met_ws"]), s)
-        call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), None, n, c, v, C.byref(self.cfg),
-             ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
+        if not fused:
+            call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
+                 C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
+                 ptr(st["met_ws"]), s)
+            call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), None, n, c, v, C.byref(self.cfg),
+                 ptr(st["coef"]), ptr(self.inv_accum), ptr(st["dlogits"]), s)
         # ---- discriminator on the 2N feature rows (train_dann.py:34-49,276-283)
         dd = [None, None, None, None]
         dinj = getattr(disc, "_mi3d_injected_drop_scales", None)          # tests: [mask after net.1, mask after net.4]
@@ -794,8 +822,13 @@ class DannStep(_StepBase):
             last = sg == nseg - 1
             exch = sg in self.comm.buckets and do_comm
             if last or exch:
-                call("mi3d_unet_backward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s),
-                     ptr(st["dlogits"]), dgs, -lam, accumulate, start, sg + 1, ptr(st["ws_s"]), st["ws_bytes"], s, None, None)
+                if fused:
+                    call("mi3d_unet_backward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s), ptr(st["y"]),
+                         C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), dgs, -lam, accumulate, start, sg + 1,
+                         ptr(st["ws_s"]), st["ws_bytes"], s, None, None)
+                else:
+                    call("mi3d_unet_backward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s),
+                         ptr(st["dlogits"]), dgs, -lam, accumulate, start, sg + 1, ptr(st["ws_s"]), st["ws_bytes"], s, None, None)
                 t0 = max(start, L + 1)            # the target graph has no decoder part
                 if sg + 1 > t0:
                     call("mi3d_unet_backward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["gtab"], ptr(drop_t),

@@ -8,6 +8,8 @@ Technique (as for the conv kernels in round 2): inputs are small DYADIC numbers 
     stored bf16 tensors to HALF A bf16 SPACING of it (<= 2^-8 relative: the kernels round, to nearest-even, an fp32 value that
     carries ~1e-7 of noise) -- i.e. every stored element is the correctly rounded result up to ties.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -350,3 +352,90 @@ def test_eight_wave_conv_is_bit_identical_to_the_four_wave_kernel(monkeypatch):
             outs.append(y.clone())
         monkeypatch.delenv("MI3D_CONV8")
         assert torch.equal(outs[0], outs[1]), (n, cin, cout, d, h, w)
+
+
+# ------------------------------------------------------------------------------------------------ head + loss in one pass
+@pytest.mark.parametrize("case", [(2, 4, 16, 16, 16, "combined"), (1, 4, 5, 7, 9, "ce_tversky"), (2, 3, 4, 6, 50, "combined"),
+                                  (3, 2, 3, 5, 37, "dice")])
+def test_head_loss_fused_passes_against_the_unfused_operators(case):
+    """mi3d_head_loss_forward / _backward (the training step's 1x1x1 head folded into the loss, models/unet.py:62,87 +
+    utils/metrics.py:14-40) against the operator chain they replace: mi3d_conv1_forward -> mi3d_seg_loss_metrics_forward and
+    mi3d_seg_loss_backward -> mi3d_conv1_backward.  The kept logits are the unfused head's bit for bit; the metrics come from
+    integer counts (exact); the loss sums the same per-voxel terms in another order (a few ulp); given the SAME coefficients the
+    fused backward is bitwise the unfused pair.  Ragged voxel counts and C < 4 included."""
+    from multimodal_segmentation_project_amd.trainer import _loss_cfg
+    n, c, d, h, w, loss = case
+    cin, v = 16, d * h * w
+    cfg = _loss_cfg(loss)
+    assert _lib.lib().mi3d_head_loss_supported(1, cin, c, C.byref(cfg)) == 1
+    g = torch.Generator().manual_seed(v + c)
+    z = (torch.randn(n, v, cin, generator=g) * 1.5).bfloat16().to(DEV)
+    wgt = (torch.randn(c, cin, generator=g) * 0.4).to(DEV)
+    bias = (torch.randn(c, generator=g) * 0.2).to(DEV)
+    lab = torch.randint(0, c, (n, v), generator=g).to(DEV)
+    lib = _lib.lib()
+    lws = torch.empty(lib.mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=DEV)
+    mws = torch.empty(lib.mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=DEV)
+    wsb = lib.mi3d_conv1_workspace_bytes(cin, c)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    scale = torch.tensor([0.5], device=DEV)
+    # unfused
+    logits = torch.empty((n, c, v), device=DEV)
+    call("mi3d_conv1_forward", 1, ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(logits), c, n, v, None)
+    met0, coef0 = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
+    call("mi3d_seg_loss_metrics_forward", ptr(logits), ptr(lab), None, n, c, d, v, C.byref(cfg), ptr(met0), ptr(coef0), ptr(met0[1:]),
+         ptr(lws), ptr(mws), None)
+    dl = torch.empty_like(logits)
+    call("mi3d_seg_loss_backward", ptr(logits), ptr(lab), None, n, c, v, C.byref(cfg), ptr(coef0), ptr(scale), ptr(dl), None)
+    dz0 = torch.empty_like(z)
+    dW0, db0 = torch.empty((c, cin), device=DEV), torch.empty(c, device=DEV)
+    call("mi3d_conv1_backward", 1, ptr(z), cin, cin, ptr(wgt), ptr(dl), c, ptr(dz0), cin, ptr(dW0), ptr(db0), 0, n, v, ptr(ws), wsb, None)
+    # fused
+    met1, coef1 = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
+    kept = torch.empty_like(logits)
+    call("mi3d_head_loss_forward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), n, c, d, v, C.byref(cfg), ptr(met1), ptr(coef1),
+         ptr(met1[1:]), ptr(lws), ptr(mws), ptr(kept), None)
+    assert torch.equal(kept, logits)
+    assert torch.equal(met1[1:], met0[1:])                                  # iou / dice / acc: from exact counts
+    assert abs(float(met1[0]) - float(met0[0])) <= 2e-6 * abs(float(met0[0]))
+    np.testing.assert_allclose(coef1.cpu().numpy(), coef0.cpu().numpy(), rtol=2e-6, atol=1e-12)
+    dz1 = torch.empty_like(z)
+    dW1, db1 = torch.empty((c, cin), device=DEV), torch.empty(c, device=DEV)
+    call("mi3d_head_loss_backward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), n, c, v, C.byref(cfg), ptr(coef0), ptr(scale),
+         ptr(dz1), cin, ptr(dW1), ptr(db1), 0, ptr(ws), wsb, None)
+    assert torch.equal(dz1.view(torch.int16), dz0.view(torch.int16))
+    assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
+    # without the optional logits copy the results do not change
+    met2, coef2 = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
+    call("mi3d_head_loss_forward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), n, c, d, v, C.byref(cfg), ptr(met2), ptr(coef2),
+         ptr(met2[1:]), ptr(lws), ptr(mws), None, None)
+    assert torch.equal(met2, met1) and torch.equal(coef2, coef1)
+
+
+def test_train_step_with_fused_head_equals_the_unfused_step(monkeypatch):
+    """TrainStep at 96^3 N=2 bf16 with the head folded into the loss (default) against MI3D_NO_HEAD_LOSS=1 (logits and dlogits
+    through memory): metrics identical, loss to a few ulp, every updated parameter within the noise of one ulp of `coef`."""
+    from multimodal_segmentation_project_amd.trainer import TrainStep
+    x, y = _synth(2, 96, 77)
+    res = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("MI3D_NO_HEAD_LOSS", "1")
+        torch.manual_seed(3)
+        m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+        ts = TrainStep(m, lr=1e-3, weight_decay=0.0, compute_dtype=torch.bfloat16)
+        assert ts._prepare(x.to(DEV))["fused_head"] == fused
+        out = ts.step(x.to(DEV), y.to(DEV)).cpu()
+        grads = {k: p.grad.detach().clone().cpu() for k, p in m.named_parameters()}
+        res.append((out, grads))
+        ts.close()
+    (o1, g1), (o0, g0) = res
+    assert torch.equal(o1[1:], o0[1:])
+    assert abs(float(o1[0]) - float(o0[0])) <= 2e-6 * abs(float(o0[0]))
+    worst = 0.0
+    for k in g0:
+        if float(g0[k].double().norm()) < 1e-7 or k.endswith("double_conv.0.bias") or k.endswith("double_conv.4.bias"):
+            continue
+        worst = max(worst, relerr(g1[k], g0[k]))
+    print("fused head vs unfused step at 96^3: worst per-tensor gradient relerr", worst)
+    assert worst < 1e-3
