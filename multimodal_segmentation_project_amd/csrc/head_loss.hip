@@ -450,6 +450,8 @@ __global__ __launch_bounds__(BLK) void seg_loss_fwd_kernel(const float* __restri
     }
 }
 
+__device__ __forceinline__ void loss_row_sum(const double* __restrict__ part, int nblk, int C, int q, int lane, double* sums);
+__device__ __forceinline__ void loss_scalars(const double* sums, int N, int C, int64_t V, LossCfg cfg, float* loss_out, float* coef);
 // one 1024-thread block: wave w sums quantities w, w+16 over the block partials (lane-strided doubles + wave tree:
 // fixed order), then thread 0 computes the loss and the gradient coefficients
 __device__ __forceinline__ void seg_loss_finalize_body(const double* __restrict__ part, int nblk, int N, int C,
@@ -459,14 +461,22 @@ __device__ __forceinline__ void seg_loss_finalize_body(const double* __restrict_
     const int nqc = 2 + 3 * C;
     if (threadIdx.x < NQ) sums[threadIdx.x] = 0.0;
     __syncthreads();
-    for (int q = wave; q < nqc; q += 16) {
-        double s = 0.0;
-        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * nqc + q];
-        s = wave_sum_d(s);
-        if (lane == 0) sums[q < 2 ? q : 2 + ((q - 2) / C) * MAXC + (q - 2) % C] = s;      // -> the MAXC layout used below
-    }
+    for (int q = wave; q < nqc; q += 16) loss_row_sum(part, nblk, C, q, lane, sums);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) loss_scalars(sums, N, C, V, cfg, loss_out, coef);
+}
+
+// quantity q of the compact partial rows, summed by one wave (lane-strided doubles + wave tree: fixed order) into the MAXC layout
+__device__ __forceinline__ void loss_row_sum(const double* __restrict__ part, int nblk, int C, int q, int lane, double* sums) {
+    const int nqc = 2 + 3 * C;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * nqc + q];
+    s = wave_sum_d(s);
+    if (lane == 0) sums[q < 2 ? q : 2 + ((q - 2) / C) * MAXC + (q - 2) % C] = s;
+}
+
+__device__ __forceinline__ void loss_scalars(const double* sums, int N, int C, int64_t V, LossCfg cfg, float* loss_out, float* coef) {
+    {
         double M = (double)N * (double)V;
         double reg = 0.0;
         double sc = C > 1 ? (double)cfg.w_reg / (double)(C - 1) : 0.0;
@@ -908,6 +918,8 @@ __global__ __launch_bounds__(BLK) void seg_metrics_kernel(const float* __restric
     }
 }
 
+__device__ __forceinline__ void count_row_sum(const unsigned long long* part, int nblk, int C, int q, int lane, unsigned long long* counts);
+__device__ __forceinline__ void metric_scalars(const unsigned long long* counts, int N, int C, int D, int64_t V, float* out);
 // Q1: the reference's class loop is range(1, pred.size(1)) AFTER argmax -> bound = first spatial dim D
 __device__ __forceinline__ void seg_metrics_finalize_body(const unsigned long long* part, int nblk, int N, int C,
                                                           int D, int64_t V, float* out) {
@@ -916,14 +928,21 @@ __device__ __forceinline__ void seg_metrics_finalize_body(const unsigned long lo
     const int ncc = 3 * C + 1;
     if (threadIdx.x < 3 * MAXC + 1) counts[threadIdx.x] = 0;
     __syncthreads();
-    for (int q = wave; q < ncc; q += 16) {                  // exact integer sums, wave-parallel
-        unsigned long long s = 0;
-        for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * ncc + q];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) counts[q == 3 * C ? 3 * MAXC : (q / C) * MAXC + q % C] = s;
-    }
+    for (int q = wave; q < ncc; q += 16) count_row_sum(part, nblk, C, q, lane, counts);     // exact integer sums, wave-parallel
     __syncthreads();
     if (threadIdx.x != 0) return;
+    metric_scalars(counts, N, C, D, V, out);
+}
+
+__device__ __forceinline__ void count_row_sum(const unsigned long long* part, int nblk, int C, int q, int lane, unsigned long long* counts) {
+    const int ncc = 3 * C + 1;
+    unsigned long long s = 0;
+    for (int b = lane; b < nblk; b += 64) s += part[(int64_t)b * ncc + q];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) counts[q == 3 * C ? 3 * MAXC : (q / C) * MAXC + q % C] = s;
+}
+
+__device__ __forceinline__ void metric_scalars(const unsigned long long* counts, int N, int C, int D, int64_t V, float* out) {
     float iou = 0.f, dice = 0.f;
     int valid = 0;
     for (int c = 1; c < D && c < C; c++) {
@@ -950,9 +969,23 @@ __global__ __launch_bounds__(1024) void seg_metrics_finalize_kernel(const unsign
 __global__ __launch_bounds__(1024) void seg_loss_metrics_finalize_kernel(const double* __restrict__ part, const unsigned long long* cnt,
                                                                          int nblk, int N, int C, int D, int64_t V, LossCfg cfg,
                                                                          float* loss_out, float* coef, float* met_out) {
-    seg_loss_finalize_body(part, nblk, N, C, V, cfg, loss_out, coef);
+    // all 2 + 3C + 3C + 1 row sums in ONE phase (two rounds of the 16 waves, every load issued before the first wait), then the
+    // two scalar tails on two waves at once: same sums in the same order as the two bodies one after the other, one
+    // memory round trip and one serial tail less on the step's dependent chain
+    __shared__ double sums[NQ];
+    __shared__ unsigned long long counts[3 * MAXC + 1];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nqc = 2 + 3 * C, ncc = 3 * C + 1;
+    if (threadIdx.x < NQ) sums[threadIdx.x] = 0.0;
+    if (threadIdx.x < 3 * MAXC + 1) counts[threadIdx.x] = 0;
     __syncthreads();
-    seg_metrics_finalize_body(cnt, nblk, N, C, D, V, met_out);
+    for (int q = wave; q < nqc + ncc; q += 16) {
+        if (q < nqc) loss_row_sum(part, nblk, C, q, lane, sums);
+        else count_row_sum(cnt, nblk, C, q - nqc, lane, counts);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) loss_scalars(sums, N, C, V, cfg, loss_out, coef);
+    if (threadIdx.x == 64) metric_scalars(counts, N, C, D, V, met_out);
 }
 
 // raw exact counts for the per-class evaluation metrics (test_model.py:242-285): out[0..C) n_inter, [C..2C) n_pred,

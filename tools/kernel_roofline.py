@@ -92,6 +92,13 @@ def model(rows, net):
             layer, what = f"upconvs.{up_f}", "ConvTranspose fwd"
             by = net.M[l + 1] * 2 * net.C[l] * 2 + net.M[l] * net.C[l] * 2 + 8 * 2 * net.C[l] * net.C[l] * 4
             fl = 2.0 * 8 * 2 * net.C[l] * net.C[l] * net.M[l + 1]
+        elif "head_loss_fwd" in n:
+            layer, what = "final_conv + loss", "1x1x1 conv + Dice/CE + metrics fwd (logits never written)"
+            by, fl = net.M[0] * (net.C[0] * 2 + 8), 2.0 * net.C[0] * 4 * net.M[0]
+        elif "head_loss_bwd" in n:
+            phase = "bwd"
+            layer, what = "final_conv + loss", "loss bwd + 1x1x1 conv bwd (dlogits never written)"
+            by, fl = net.M[0] * (net.C[0] * 2 + 8 + net.C[0] * 2), 2.0 * 3 * net.C[0] * 4 * net.M[0]
         elif "conv1_fwd" in n:
             layer, what, by, fl = "final_conv", "1x1x1 conv fwd", net.M[0] * (net.C[0] * 2 + 4 * 4), 2.0 * net.C[0] * 4 * net.M[0]
         elif "seg_loss_fwd" in n:
