@@ -439,3 +439,34 @@ def test_train_step_with_fused_head_equals_the_unfused_step(monkeypatch):
         worst = max(worst, relerr(g1[k], g0[k]))
     print("fused head vs unfused step at 96^3: worst per-tensor gradient relerr", worst)
     assert worst < 1e-3
+
+
+def test_fused_head_is_refused_where_it_has_no_kernels():
+    """fp32 activations, a distillation term or > 4 classes have no fused head + loss kernels: mi3d_unet_head_loss_supported says
+    so, the fused entry points fail loudly (no silent fallback inside the library), and TrainStep takes the four-call sequence."""
+    from multimodal_segmentation_project_amd.trainer import TrainStep, _loss_cfg
+    from multimodal_segmentation_project_amd._lib import Mi3dError
+    lib = _lib.lib()
+    cfg = _loss_cfg("combined")
+    assert lib.mi3d_head_loss_supported(1, 16, 4, C.byref(cfg)) == 1
+    assert lib.mi3d_head_loss_supported(0, 16, 4, C.byref(cfg)) == 0          # fp32
+    assert lib.mi3d_head_loss_supported(1, 16, 5, C.byref(cfg)) == 0          # 5 classes
+    assert lib.mi3d_head_loss_supported(1, 32, 4, C.byref(cfg)) == 0          # backward needs features[0] == 16
+    kd = _loss_cfg("combined", 0.7, 2.0)
+    assert lib.mi3d_head_loss_supported(1, 16, 4, C.byref(kd)) == 0           # distillation term
+    z = torch.zeros((1, 64, 16), dtype=torch.bfloat16, device=DEV)
+    w, b = torch.zeros((5, 16), device=DEV), torch.zeros(5, device=DEV)
+    lab = torch.zeros((1, 64), dtype=torch.int64, device=DEV)
+    out, coef = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
+    lws = torch.empty(lib.mi3d_seg_loss_workspace_bytes(5), dtype=torch.uint8, device=DEV)
+    with pytest.raises(Mi3dError):
+        call("mi3d_head_loss_forward", ptr(z), 16, 16, ptr(w), ptr(b), ptr(lab), 1, 5, 4, 64, C.byref(cfg), ptr(out), ptr(coef), None,
+             ptr(lws), None, None, None)
+    torch.manual_seed(0)
+    m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+    ts = TrainStep(m, lr=1e-3, compute_dtype=torch.float32)
+    x, y = _synth(1, 16, 5)
+    assert ts._prepare(x.to(DEV))["fused_head"] is False
+    o = ts.step(x.to(DEV), y.to(DEV))
+    assert torch.isfinite(o).all()
+    ts.close()
