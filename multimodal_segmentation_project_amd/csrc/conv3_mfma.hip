@@ -1608,36 +1608,70 @@ __global__ __launch_bounds__(BLK) void conv3_wgrad_c1_kernel(const float* __rest
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     float dbs = 0.f;
     int ntiles = N * tilesZ * tilesY * tilesX;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // tile-invariant staging maps + register prefetch of the next tile (as conv3_wgrad_body / conv3_c1_fwd_mfma_kernel):
+    //   dy  slot it = z-slice it; thread t -> (iy, ix) = ((t >> 1) / 16, (t >> 1) % 16), channel half t & 1
+    //   x   slot s of thread t = halo element t + 256 s -> (row, h)
+    static_assert(WTY * WTX * 2 == BLK, "one z-slice of dy per staging slot");
+    const int hv = threadIdx.x >> 1, hf = threadIdx.x & 1;
+    const int a_iy = hv / WTX, a_ix = hv % WTX;
+    const int a_rel = (a_iy * W + a_ix) * dycs + hf * 8;
+    constexpr int NS = (C1_ROWS * WIX + BLK - 1) / BLK;
+    int s_rel[NS], s_pk[NS];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++) {
+        int idx = threadIdx.x + s_ * BLK;
+        bool act = idx < C1_ROWS * WIX;
+        int h = act ? idx % WIX : 0, row = act ? idx / WIX : 0;
+        int iy = row % WIY, iz = row / WIY;
+        s_rel[s_] = (iz * H + iy) * W + h;
+        s_pk[s_] = iz | (iy << 4) | (h << 8) | (row << 16) | (act ? (1 << 24) : 0);
+    }
+    bf16x8 va[WTZ];
+    float xv[NS];
+    auto load_tile = [&](int tile) {
         int t = tile;
         int tx_ = t % tilesX; t /= tilesX;
         int ty_ = t % tilesY; t /= tilesY;
         int tz_ = t % tilesZ; int n = t / tilesZ;
         int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < WNV * 2; idx += BLK) {
-            int half = idx & 1, vox = idx >> 1;
-            int ix = vox % WTX, tt = vox / WTX, iy = tt % WTY, iz = tt / WTY;
-            int gz = z0 + iz, gy = y0 + iy, gx = x0 + ix;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gz < D && gy < H && gx < W)
-                v = *reinterpret_cast<const bf16x8*>(dy + ((((int64_t)n * D + gz) * H + gy) * W + gx) * dycs + co0 + half * 8);
-            *reinterpret_cast<bf16x8*>(dys + vox * 16 + half * 8) = v;
-        }
-        for (int idx = threadIdx.x; idx < C1_ROWS * WIX; idx += BLK) {
-            int h = idx % WIX, row = idx / WIX;
-            int iy = row % WIY, iz = row / WIY;
-            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + h;
-            float v = 0.f;
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[(((int64_t)n * D + gz) * H + gy) * W + gx];
-            bf16 vb = (bf16)v;
+        const bf16* dyb = dy + ((((int64_t)n * D + z0) * H + y0) * W + x0) * dycs + co0;
+        const int64_t a_zs = (int64_t)H * W * dycs;
+        bool a_ok = y0 + a_iy < H && x0 + a_ix < W;
 #pragma unroll
-            for (int dx = 0; dx < 3; dx++) {           // copy dx holds x[.. + xx + dx] at xx = h - dx
-                int xx = h - dx;
-                if (xx >= 0 && xx < 16) xsh[(dx * C1_ROWS + row) * 16 + xx] = vb;
+        for (int it = 0; it < WTZ; it++) {
+            va[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (a_ok && z0 + it < D) va[it] = *reinterpret_cast<const bf16x8*>(dyb + it * a_zs + a_rel);
+        }
+        const float* xb = x + (((int64_t)n * D + (z0 - 1)) * H + (y0 - 1)) * W + (x0 - 1);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; s_++) {
+            int pk = s_pk[s_];
+            bool ok = (pk >> 24) && (unsigned)(z0 - 1 + (pk & 15)) < (unsigned)D && (unsigned)(y0 - 1 + ((pk >> 4) & 15)) < (unsigned)H &&
+                      (unsigned)(x0 - 1 + ((pk >> 8) & 31)) < (unsigned)W;
+            xv[s_] = 0.f;
+            if (ok) xv[s_] = xb[s_rel[s_]];
+        }
+    };
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < WTZ; it++) *reinterpret_cast<bf16x8*>(dys + (threadIdx.x + it * BLK) * 8) = va[it];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; s_++) {
+            int pk = s_pk[s_];
+            if (pk >> 24) {
+                int h = (pk >> 8) & 31, row = (pk >> 16) & 255;
+                bf16 vb = (bf16)xv[s_];
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {           // copy dx holds x[.. + xx + dx] at xx = h - dx
+                    int xx = h - dx;
+                    if (xx >= 0 && xx < 16) xsh[(dx * C1_ROWS + row) * 16 + xx] = vb;
+                }
             }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 #pragma unroll
         for (int z = 0; z < WTZ; z++) {
             bf16x8 A = tr_frag(dysb, laneA + z * (WTY * WTX * 32));
@@ -1714,6 +1748,38 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
     int ntiles = N * tilesZ * tilesY * tilesX;
     // pad elements (index > 17 - shift) are never written by the staging loop: zero them once, they meet zero weights
     for (int idx = threadIdx.x; idx < 4 * ROWS * C1F_LD; idx += BLK) xsh[idx] = (bf16)0.f;
+    // staging map, tile-invariant (round 3: it was re-derived by constant division for every element of every tile, and the
+    // loads were consumed where they were issued): slot s of thread t = halo element t + 256 s -> (row, h); the next tile's
+    // elements are prefetched into registers under this tile's MFMAs and stores
+    constexpr int NS = (ROWS * WIX + BLK - 1) / BLK;
+    int s_rel[NS], s_pk[NS];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; s_++) {
+        int idx = threadIdx.x + s_ * BLK;
+        bool act = idx < ROWS * WIX;
+        int h = act ? idx % WIX : 0, row = act ? idx / WIX : 0;
+        int iy = row % WIY, iz = row / WIY;
+        s_rel[s_] = (iz * H + iy) * W + h;
+        s_pk[s_] = iz | (iy << 4) | (h << 8) | (row << 16) | (act ? (1 << 24) : 0);
+    }
+    float xv[NS];
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        int tx_ = t % tilesX; t /= tilesX;
+        int ty_ = t % tilesY; t /= tilesY;
+        int tz_ = t % tilesZ; int n = t / tilesZ;
+        int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
+        const float* xb = x + (((int64_t)n * D + (z0 - 1)) * H + (y0 - 1)) * W + (x0 - 1);      // halo origin; only in-range lanes load
+#pragma unroll
+        for (int s_ = 0; s_ < NS; s_++) {
+            int pk = s_pk[s_];
+            bool ok = (pk >> 24) && (unsigned)(z0 - 1 + (pk & 15)) < (unsigned)D && (unsigned)(y0 - 1 + ((pk >> 4) & 15)) < (unsigned)H &&
+                      (unsigned)(x0 - 1 + ((pk >> 8) & 31)) < (unsigned)W;
+            xv[s_] = 0.f;
+            if (ok) xv[s_] = xb[s_rel[s_]];
+        }
+    };
+    if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int t = tile;
         int tx_ = t % tilesX; t /= tilesX;
@@ -1721,20 +1787,21 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
         int tz_ = t % tilesZ; int n = t / tilesZ;
         int z0 = tz_ * WTZ, y0 = ty_ * WTY, x0 = tx_ * WTX;
         __syncthreads();
-        for (int idx = threadIdx.x; idx < ROWS * WIX; idx += BLK) {
-            int h = idx % WIX, row = idx / WIX;
-            int iy = row % WIY, iz = row / WIY;
-            int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + h;
-            float v = 0.f;
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[(((int64_t)n * D + gz) * H + gy) * W + gx];
-            bf16 vb = (bf16)v;
 #pragma unroll
-            for (int sft = 0; sft < 4; sft++) {              // copy sft holds x[i + sft] at i
-                int i = h - sft;
-                if (i >= 0) xsh[(sft * ROWS + row) * C1F_LD + i] = vb;
+        for (int s_ = 0; s_ < NS; s_++) {
+            int pk = s_pk[s_];
+            if (pk >> 24) {
+                int h = (pk >> 8) & 31, row = (pk >> 16) & 255;
+                bf16 vb = (bf16)xv[s_];
+#pragma unroll
+                for (int sft = 0; sft < 4; sft++) {              // copy sft holds x[i + sft] at i
+                    int i = h - sft;
+                    if (i >= 0) xsh[(sft * ROWS + row) * C1F_LD + i] = vb;
+                }
             }
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
         int gz = z0 + wave, gx = x0 + vn;
         bool okzx = gz < D && gx < W;
         bf16* yrow = y + ((((int64_t)n * D + gz) * H + y0) * W + gx) * ycs + co0 + kg * 4;
@@ -2046,7 +2113,7 @@ int conv3_mfma_wgrad_c1(const float* x, const void* dy, int dycs, int Cout, Geo 
 // sums [conv3_c1_fwd_stat_blocks][2][Cout] of the stored (rounded) values
 int conv3_c1_fwd_stat_blocks(Geo g) {
     int64_t ntiles = (int64_t)g.N * cdiv(g.D, WTZ) * cdiv(g.H, WTY) * cdiv(g.W, WTX);
-    return (int)(ntiles < 1024 ? ntiles : 1024);        // round 3: 512 measured +10 us
+    return (int)(ntiles < 1024 ? ntiles : 1024);        // round 3 (ms/step): 512: +10 us; 768: =; 2048: +3 us kernel; 3456: +8 us kernel
 }
 int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y, int ycs, int Cout, Geo g, float* part,
                       hipStream_t s, const float* wscale, int relu) {
