@@ -229,27 +229,31 @@ __device__ __forceinline__ void upconv_mfma_bwd_weight_body(UBid bid_, const bf1
     int64_t M = (int64_t)N * D * H * W;
     int64_t ntile = (M + UV - 1) / UV;
     constexpr int NA = (2 * UV * 2) / BLK, NB = (2 * 8 * UV * 2) / BLK;
+    static_assert(UV * 2 == BLK && NA == 2 && NB == 16, "staging map: slot it of thread t = (block/tap it, voxel t >> 1, half t & 1)");
     bf16x8 va[NA], vb[NB];
+    // Every staging slot of a thread belongs to the SAME voxel (t >> 1): slot it of x is ci-block it, slot it of g is
+    // (co-block it / 8, tap it % 8).  One voxel decomposition per tile (round 3: there was one per slot -- three runtime divisions
+    // x 16 slots = ~1000 vector instructions per tile against 32 MFMAs), the 16 tap / block offsets are scalars.
+    const int hv = threadIdx.x >> 1, hf = threadIdx.x & 1;
     auto load_tile = [&](int64_t tile) {
+        int64_t v = tile * UV + hv;
+        bool ok = v < M;
+        unsigned vu = (unsigned)(ok ? v : 0);
+        int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H;
+        int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
+        const bf16* xp = x + v * xcs + ci0 + hf * 8;
+        const bf16* gp = g + ((((int64_t)n * 2 * D + 2 * d_) * 2 * H + 2 * h_) * 2 * W + 2 * w_) * gcs + co0 + hf * 8;
 #pragma unroll
         for (int it = 0; it < NA; it++) {
-            int idx = threadIdx.x + it * BLK;
-            int half = idx & 1, vox = (idx >> 1) % UV, cb = (idx >> 1) / UV;
-            int64_t v = tile * UV + vox;
             va[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (v < M) va[it] = *reinterpret_cast<const bf16x8*>(x + v * xcs + ci0 + cb * 16 + half * 8);
+            if (ok) va[it] = *reinterpret_cast<const bf16x8*>(xp + it * 16);
         }
 #pragma unroll
         for (int it = 0; it < NB; it++) {
-            int idx = threadIdx.x + it * BLK;
-            int half = idx & 1, vox = (idx >> 1) % UV, r2 = (idx >> 1) / UV, tap = r2 % 8, cb = r2 / 8;
-            int64_t v = tile * UV + vox;
+            const int tap = it % 8, cb = it / 8;
+            const int ta = tap >> 2, tb = (tap >> 1) & 1, tc = tap & 1;
             vb[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (v < M && cb < cbn) {
-                unsigned vu = (unsigned)v; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
-                int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
-                vb[it] = *reinterpret_cast<const bf16x8*>(g + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + c) * gcs + co0 + cb * 16 + half * 8);
-            }
+            if (ok && cb < cbn) vb[it] = *reinterpret_cast<const bf16x8*>(gp + (((int64_t)ta * 2 * H + tb) * 2 * W + tc) * gcs + cb * 16);
         }
     };
     // the next tile's global loads are issued before this tile's MFMAs (register prefetch)
@@ -432,7 +436,11 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         while (gx * gy < 512 && gy < Cin / 16) gy *= 2;
         int64_t gkx = cdiv(g.M(), 16);
         bool ksp = gx * gy < 512 && Cout / 4 >= 8 && gkx * (Cin / 16) <= 8192;
-        const int wcap = 256, dcap = 256;                    // one workgroup of each kind per CU (measured best; round 3: 128 / 512 of either: neutral to +20 us)
+        // about one workgroup of each kind per CU; fewer weight-gradient workgroups where a slab is big (round 3 scan of the cap
+        // 128 / 192 / 256 / 384, kernel us: 32->16 35.9 / 33.7 / 29.7 / 39.1, 64->32 25.5 / 24.9 / 27.8 / 30.1, 128->64 20.2 / 21.1 / 22.6 / 22.5;
+        // data-gradient cap 128 / 512: +6 ... +14 us)
+        const int64_t nWs = (int64_t)Cin * Cout * 8;
+        const int wcap = nWs >= 65536 ? 128 : nWs >= 16384 ? 192 : 256, dcap = 256;
         int groups = (Cin / 32) * (int)cdiv(Cout, 32);
         int64_t ntile = (g.M() + UV - 1) / UV;
         int64_t want = cdiv((int64_t)wcap, (int64_t)groups);
