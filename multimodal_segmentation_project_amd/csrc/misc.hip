@@ -166,22 +166,57 @@ __global__ void softmax_ce_rows_kernel(const float* __restrict__ logits, const i
 
 // (Round 3: folding the step increment into this kernel -- last block to finish, atomicInc ticket -- made it 58 instead of 29 us:
 // 4096 arrivals on one word serialise at ~88 per us.  The one-thread step_inc_kernel launch (4 us) stays.)
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             int64_t n, float lr, float b1, float b2, float eps, float wd, float grad_scale,
-                             const int64_t* __restrict__ step_dev) {
+// 16-byte accesses, the next iteration's four loads in flight under the current update, and the first loads issued BEFORE the
+// double-precision bias corrections (two pow + sqrt, ~1 us of dependent arithmetic that every wave repeats): round 3, 32.5 -> see
+// DESIGN.  Per element the arithmetic is unchanged (bit-identical parameters).
+__device__ __forceinline__ void adamw_one(float& pi, float gi, float& mi, float& vi, float lr, float b1, float b2, float eps, float wd,
+                                          float grad_scale, float bc2s, float step_size) {
+    gi = gi * grad_scale;
+    pi = pi * (1.f - lr * wd);
+    mi = b1 * mi + (1.f - b1) * gi;       // torch: exp_avg.lerp_(grad, 1-b1)
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    float denom = sqrtf(vi) / bc2s + eps;
+    pi = pi - step_size * (mi / denom);
+}
+__global__ __launch_bounds__(BLK) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                                    float grad_scale, const int64_t* __restrict__ step_dev) {
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int64_t n4 = vec ? n >> 2 : 0, stride = (int64_t)gridDim.x * BLK;
+    int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    float4 g4, p4, m4, v4;
+    bool have = i < n4;
+    if (have) {
+        g4 = reinterpret_cast<const float4*>(g)[i]; p4 = reinterpret_cast<const float4*>(p)[i];
+        m4 = reinterpret_cast<const float4*>(m)[i]; v4 = reinterpret_cast<const float4*>(v)[i];
+    }
     double step = (double)(*step_dev + 1);
     float bc1 = (float)(1.0 - pow((double)b1, step));
     float bc2s = (float)sqrt(1.0 - pow((double)b2, step));
     float step_size = lr / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
-        float gi = g[i] * grad_scale;
-        float pi = p[i] * (1.f - lr * wd);
-        float mi = b1 * m[i] + (1.f - b1) * gi;       // torch: exp_avg.lerp_(grad, 1-b1)
-        float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        float denom = sqrtf(vi) / bc2s + eps;
-        p[i] = pi - step_size * (mi / denom);
+    while (have) {
+        int64_t j = i + stride;
+        bool have2 = j < n4;
+        float4 g5, p5, m5, v5;
+        if (have2) {
+            g5 = reinterpret_cast<const float4*>(g)[j]; p5 = reinterpret_cast<const float4*>(p)[j];
+            m5 = reinterpret_cast<const float4*>(m)[j]; v5 = reinterpret_cast<const float4*>(v)[j];
+        }
+        adamw_one(p4.x, g4.x, m4.x, v4.x, lr, b1, b2, eps, wd, grad_scale, bc2s, step_size);
+        adamw_one(p4.y, g4.y, m4.y, v4.y, lr, b1, b2, eps, wd, grad_scale, bc2s, step_size);
+        adamw_one(p4.z, g4.z, m4.z, v4.z, lr, b1, b2, eps, wd, grad_scale, bc2s, step_size);
+        adamw_one(p4.w, g4.w, m4.w, v4.w, lr, b1, b2, eps, wd, grad_scale, bc2s, step_size);
+        reinterpret_cast<float4*>(m)[i] = m4;
+        reinterpret_cast<float4*>(v)[i] = v4;
+        reinterpret_cast<float4*>(p)[i] = p4;
+        i = j; have = have2; g4 = g5; p4 = p5; m4 = m5; v4 = v5;
+    }
+    // scalar tail (and the whole range when a pointer is not 16-byte aligned)
+    for (int64_t k = n4 * 4 + (int64_t)blockIdx.x * BLK + threadIdx.x; k < n; k += stride) {
+        float pi = p[k], mi = m[k], vi = v[k];
+        adamw_one(pi, g[k], mi, vi, lr, b1, b2, eps, wd, grad_scale, bc2s, step_size);
+        m[k] = mi; v[k] = vi; p[k] = pi;
     }
 }
 __global__ void step_inc_kernel(int64_t* step_dev) { *step_dev += 1; }
@@ -289,7 +324,7 @@ int softmax_ce_rows(const float* logits, const int64_t* labels, int M, int C, fl
 int adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                float wd, float grad_scale, int64_t* step_dev, hipStream_t s, int increment) {
     if (n > 0) {
-        adamw_kernel<<<sgrid(n, 4096), BLK, 0, s>>>(p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step_dev);
+        adamw_kernel<<<sgrid((n + 3) / 4, 2048), BLK, 0, s>>>(p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step_dev);
         MI3D_LAUNCH_CHECK();
     }
     if (increment) {
