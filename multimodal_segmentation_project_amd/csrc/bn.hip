@@ -427,9 +427,13 @@ __global__ __launch_bounds__(BLK) void bn_bwd_reduce_slab_kernel(int nred, const
                                                                  int ycs, int C, int64_t M, int64_t V,
                                                                  const float* __restrict__ stat,
                                                                  const float* __restrict__ drop, float* __restrict__ part, SlabJob job,
-                                                                 const float* __restrict__ skp, int ks) {
+                                                                 SlabJob job2, const float* __restrict__ skp, int ks) {
     if ((int)blockIdx.x < nred) bn_bwd_reduce_body<T, VEC>(nred, dz, dzcs, y, ycs, C, M, V, stat, drop, part, skp, ks);
-    else slab_job_run(job, (int)blockIdx.x - nred);
+    else {
+        int b = (int)blockIdx.x - nred;
+        if (b < job.nblocks) slab_job_run(job, b);
+        else slab_job_run(job2, b - job.nblocks);
+    }
 }
 
 // coef[3][C] = {c1 = sum_dyh / M, c2 = sum_dyh_xhat / M, g = gamma*invstd(=a)}; dgamma, dbeta (+)=
@@ -672,7 +676,7 @@ int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, flo
 
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta, int accumulate,
-           float* ws, hipStream_t s, const SlabJob* extra, const float* skp, int ks) {
+           float* ws, hipStream_t s, const SlabJob* extra, const float* skp, int ks, const SlabJob* extra2) {
     MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_bwd: bad C=%d", C);
     MI3D_CHECK_ARG(!drop || M < (1ll << 32), "bn_bwd: dropout path needs M < 2^32 (32-bit sample index)");
     float* part = ws;
@@ -686,9 +690,10 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
         if (small) nblk = bn_small_rows(nblk, C);
         size_t lds = (size_t)2 * R * C * sizeof(float);
         if (extra && extra->nblocks > 0) {
-            int tot = nblk + extra->nblocks;
-            if (v8) bn_bwd_reduce_slab_kernel<T, 8><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra, skp, ks);
-            else bn_bwd_reduce_slab_kernel<T, 1><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra, nullptr, 0);
+            SlabJob j2 = (extra2 && extra2->nblocks > 0) ? *extra2 : SlabJob();
+            int tot = nblk + extra->nblocks + j2.nblocks;
+            if (v8) bn_bwd_reduce_slab_kernel<T, 8><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra, j2, skp, ks);
+            else bn_bwd_reduce_slab_kernel<T, 1><<<tot, BLK, lds, s>>>(nblk, (const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, *extra, j2, nullptr, 0);
         } else if (v8) bn_bwd_reduce_kernel<T, 8><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, skp, ks);
         else bn_bwd_reduce_kernel<T, 1><<<nblk, BLK, lds, s>>>((const T*)dz, dzcs, (const T*)y, ycs, C, M, V, stat, drop, part, nullptr, 0);
         MI3D_LAUNCH_CHECK();

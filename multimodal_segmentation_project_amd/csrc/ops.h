@@ -133,7 +133,8 @@ int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, flo
 // dy = gamma*invstd*(dyh - mean(dyh) - xhat*mean(dyh*xhat)), dyh = dz*drop*[a*y+b > 0]; dgamma, dbeta (+)=
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
-           int accumulate, float* ws, hipStream_t s, const SlabJob* extra = nullptr, const float* skp = nullptr, int ks = 0);
+           int accumulate, float* ws, hipStream_t s, const SlabJob* extra = nullptr, const float* skp = nullptr, int ks = 0,
+           const SlabJob* extra2 = nullptr);
 // skp != NULL: dz is still the ks fp32 split-K partials [ks][M][C] of the conv that produced it; the reduction sums and
 // rounds them and WRITES dz (the split-K finishing launch of that conv is skipped by the caller)
 // extra: a pending slab sum that rides in the reduction kernel's launch (extra blocks)

@@ -201,17 +201,27 @@ struct Ctx {
     // with its own launch when another one arrives first / at the end of the call)
     mutable SlabJob pend;
     mutable bool has_pend = false;
+    // a second pending sum (reading the SECOND slab workspace): the decoder conv's sum stays pending across the transposed
+    // conv's backward launch, and the next BatchNorm-backward reduction carries both
+    mutable SlabJob pend2;
+    mutable bool has_pend2 = false;
     bool defer_slabs = false;
     // called before ANY launch that writes the (single) slab workspace: an older pending sum must read it first.
     // Returns where the launcher may leave its own slab sum instead of launching it (NULL: launch immediately)
     SlabJob* pend_slot() const {
         if (has_pend) { slab_job_launch(pend, s); has_pend = false; }
+        if (has_pend2) { slab_job_launch(pend2, s); has_pend2 = false; }
         if (!defer_slabs) return nullptr;
         pend = SlabJob();
         return &pend;
     }
     void pend_filled() const { has_pend = defer_slabs && pend.nblocks > 0; }
-    int flush_pend() const { int rc = 0; if (has_pend) { rc = slab_job_launch(pend, s); has_pend = false; } return rc; }
+    int flush_pend() const {
+        int rc = 0;
+        if (has_pend) { rc = slab_job_launch(pend, s); has_pend = false; }
+        if (has_pend2) { int r2 = slab_job_launch(pend2, s); has_pend2 = false; if (!rc) rc = r2; }
+        return rc;
+    }
     template <typename T = void> T* at(size_t off) const { return reinterpret_cast<T*>(ws + off); }
     const float* P(int i) const { return reinterpret_cast<const float*>(params[i]); }
 };
@@ -327,8 +337,10 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         int dcs = h == 1 ? dzcs : H.Cout;
         MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
                         drop ? drop + H.drop_off : nullptr, dyb, H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
-                        c.at<float>(p.bnws), c.s, c.has_pend ? &c.pend : nullptr, h == 0 ? dz_skp : nullptr, h == 0 ? dz_ks : 0));
+                        c.at<float>(p.bnws), c.s, c.has_pend ? &c.pend : (c.has_pend2 ? &c.pend2 : nullptr), h == 0 ? dz_skp : nullptr,
+                        h == 0 ? dz_ks : 0, (c.has_pend && c.has_pend2) ? &c.pend2 : nullptr));
         c.has_pend = false;
+        c.has_pend2 = false;
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
         void* dx_f = h == 1 ? c.at(p.sC) : dxin;
@@ -699,6 +711,18 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
             if (p.resize[l]) {       // adjoint of the nearest resize in front of the concat (models/unet.py:81-83)
                 MI3D_TRY(nearest_resize_bwd(p.dt, gup, gupcs, p.C[l], p.geo[l], c.at(p.uptmp), p.C[l], p.up_geo(l), c.s));
                 gup = c.at(p.uptmp); gupcs = p.C[l];
+            }
+            // the decoder conv's pending slab sum (it reads wgws) stays pending across the transposed conv's backward, which
+            // therefore writes its slabs to the second workspace; the next BatchNorm-backward reduction carries both sums: one
+            // chain link less per level (not with the two-stream weight gradients, which own that workspace)
+            const bool keep = p.up_mfma[i] && c.has_pend && !c.has_pend2 && c.defer_slabs && !c.s2 && !getenv("MI3D_NO_UPBWD_CARRY");
+            if (p.up_mfma[i] && keep) {
+                c.pend2 = SlabJob();
+                MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gup, gupcs, p.C[l],
+                                          c.at(p.upw[i]), c.at(p.gz[l + 1]), 2 * p.C[l], G(p.up_pidx(i)), G(p.up_pidx(i) + 1),
+                                          accumulate, c.at<float>(p.wgws2), p.wgws_floats, p.geo[l + 1], c.s, &c.pend2));
+                c.has_pend2 = c.pend2.nblocks > 0;
+                continue;
             }
             SlabJob* ps = c.pend_slot();
             if (p.up_mfma[i]) {
