@@ -247,6 +247,13 @@ def test_round2_routes_are_invisible_at_the_headline_shape(monkeypatch):
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
     monkeypatch.delenv("MI3D_NO_DEFER_TAIL")
+    # round 3: which launch carries a weight-gradient slab sum changes nothing in the sum
+    monkeypatch.setenv("MI3D_NO_UPBWD_CARRY", "1")
+    l1, o1, g1 = run()
+    assert l1 == l0 and torch.equal(o1, o0)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    monkeypatch.delenv("MI3D_NO_UPBWD_CARRY")
     for sw in ("MI3D_NO_FUSED_BWD_BIG", "MI3D_NO_FUSED_BWD_P"):
         monkeypatch.setenv(sw, "1")
         l2, o2, g2 = run()
