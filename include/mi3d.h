@@ -70,7 +70,8 @@ int64_t mi3d_unet_dropout_count(const mi3d_unet_desc* d);
  * two forwards of ONE model on two streams (train_dann.py:268-272: source then target): the second one's updates of the
  * shared buffers are applied after both have run, in the reference's order, bit-identically to the serial execution.
  * drop_scales: device float[mi3d_unet_dropout_count] holding 0 or 1/(1-p), or NULL (p = 0 / eval).
- * logits: device float (N,out_channels,D,H,W).  gap_out: device float (N, 2*features[L-1]) or NULL
+ * logits: device float (N,out_channels,D,H,W), or NULL: the 1x1x1 head is not run (DANN target pass, whose logits nobody reads;
+ * or the caller runs head + loss with mi3d_unet_head_loss_forward).  gap_out: device float (N, 2*features[L-1]) or NULL
  * (unet_dann.py:77-79).  The workspace keeps everything backward needs until the next forward. */
 int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
                       const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
@@ -83,7 +84,7 @@ int mi3d_unet_bn_apply_deferred(const mi3d_unet_desc* d, void* const* buffers, c
  * eval-mode BatchNorm3d is folded into the preceding Conv3d (filter * gamma/sqrt(running_var+eps) at pack time, bias
  * replaced), ReLU runs in the conv epilogue, Dropout3d is the identity, and each conv writes the activated tensor
  * directly -- no raw conv outputs, statistics or saved activations.  Same workspace size as mi3d_unet_forward; buffers
- * (running statistics) are read-only here. */
+ * (running statistics) are read-only here.  logits = NULL: as for mi3d_unet_forward. */
 int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers, float* logits,
                     float* gap_out, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -148,32 +149,41 @@ int mi3d_seg_loss_backward(const float* logits, const int64_t* labels, const flo
 int mi3d_seg_loss_metrics_forward(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int D,
                                   int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out,
                                   void* loss_workspace, void* metrics_workspace, void* stream);
-/* The training step (train_unet.py:224-232, train_dann.py:268-281) uses the logits only inside the loss, so the 1x1x1 head
- * (models/unet.py:62,87) and the loss can be one pass each way and neither logits nor dlogits ever reach memory:
- *   mi3d_unet_forward_loss  = mi3d_unet_forward + mi3d_seg_loss_metrics_forward   (logits_opt: NULL, or where to keep them)
- *   mi3d_unet_backward_loss = mi3d_seg_loss_backward + mi3d_unet_backward         (grad_scale: device float[1] or NULL = 1)
+/* The training step (train_unet.py:224-232, train_dann.py:268-281, distill_unet.py:107-115) uses the logits only inside the loss,
+ * so the 1x1x1 head (models/unet.py:62,87) and the loss can be one pass each way and neither logits nor dlogits ever reach memory:
+ *   mi3d_unet_forward_loss      = mi3d_unet_forward + mi3d_seg_loss_metrics_forward   (logits_opt: NULL, or where to keep them)
+ *   mi3d_unet_head_loss_forward = the head + loss part alone, on the decoder output that mi3d_unet_forward / mi3d_unet_infer called
+ *                                 with logits = NULL left in the workspace (distillation: the teacher's forward runs on another
+ *                                 stream and is joined in between; evaluation: infer, then this)
+ *   mi3d_unet_backward_loss     = mi3d_seg_loss_backward + mi3d_unet_backward         (grad_scale: device float[1] or NULL = 1)
+ * teacher_logits: (N,C,V) float, required iff cfg->w_kd != 0 (distillation_loss, utils/metrics.py:169-190), else NULL.
  * Every logit has the bits of the unfused head; the forward sums add the voxels in another order (loss equal to a few ulp,
  * the integer counts behind the metrics exactly), the backward is bit-identical to the unfused pair given the same `coef`.
  * mi3d_unet_head_loss_supported: 1 if the configuration has the fused kernels (bf16 activations, features[0] == 16,
- * <= 4 classes, no distillation term), else 0 and the two calls fail with MI3D_EINVAL. */
+ * <= 4 classes), else 0 and the calls fail with MI3D_EINVAL. */
 int mi3d_unet_head_loss_supported(const mi3d_unet_desc* d, const mi3d_loss_cfg* cfg);
 /* The two fused passes as operators (z: the decoder output, channels-last bf16 (N,V,zcs); w (C,Cin), bias (C) float;
  * workspace of mi3d_head_loss_backward: mi3d_conv1_workspace_bytes(Cin, C)). */
 int mi3d_head_loss_supported(int dtype, int Cin, int C, const mi3d_loss_cfg* cfg);
-int mi3d_head_loss_forward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
-                           int D, int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out,
-                           void* loss_workspace, void* metrics_workspace, float* logits_opt, void* stream);
-int mi3d_head_loss_backward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
-                            int64_t V, const mi3d_loss_cfg* cfg, const float* coef, const float* grad_scale, void* dz, int dzcs,
-                            float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+int mi3d_head_loss_forward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels,
+                           const float* teacher, int N, int C, int D, int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef,
+                           float* metrics_out, void* loss_workspace, void* metrics_workspace, float* logits_opt, void* stream);
+int mi3d_head_loss_backward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels,
+                            const float* teacher, int N, int C, int64_t V, const mi3d_loss_cfg* cfg, const float* coef,
+                            const float* grad_scale, void* dz, int dzcs, float* dW, float* db, int accumulate, void* workspace,
+                            size_t workspace_bytes, void* stream);
 int mi3d_unet_forward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
-                           const float* drop_scales, int training, const int64_t* labels, const mi3d_loss_cfg* cfg,
-                           float* loss_out, float* coef, float* metrics_out, void* loss_workspace, void* metrics_workspace,
-                           float* logits_opt, float* gap_out, void* workspace, size_t workspace_bytes, void* stream);
+                           const float* drop_scales, int training, const int64_t* labels, const float* teacher_logits,
+                           const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out, void* loss_workspace,
+                           void* metrics_workspace, float* logits_opt, float* gap_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int mi3d_unet_head_loss_forward(const mi3d_unet_desc* d, const void* const* params, const int64_t* labels, const float* teacher_logits,
+                                const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out, void* loss_workspace,
+                                void* metrics_workspace, float* logits_opt, void* workspace, size_t workspace_bytes, void* stream);
 int mi3d_unet_backward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
-                            const float* drop_scales, const int64_t* labels, const mi3d_loss_cfg* cfg, const float* coef,
-                            const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin, int seg_end,
-                            void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events);
+                            const float* drop_scales, const int64_t* labels, const float* teacher_logits, const mi3d_loss_cfg* cfg,
+                            const float* coef, const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin,
+                            int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events);
 size_t mi3d_seg_metrics_workspace_bytes(int C);
 /* out: device float[3] = {iou, dice, accuracy}; D = first spatial dim (reference loop bound, metrics.py:74,101) */
 int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,

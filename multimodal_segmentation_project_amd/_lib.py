@@ -67,10 +67,11 @@ _SIGS = {
     "mi3d_seg_loss_metrics_forward": (i32, [vp, vp, vp, i32, i32, i32, i64, _LP, vp, vp, vp, vp, vp, vp]),
     "mi3d_unet_head_loss_supported": (i32, [_DP, _LP]),
     "mi3d_head_loss_supported": (i32, [i32, i32, i32, _LP]),
-    "mi3d_head_loss_forward": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i64, _LP, vp, vp, vp, vp, vp, vp, vp]),
-    "mi3d_head_loss_backward": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
-    "mi3d_unet_forward_loss": (i32, [_DP, vp, vp, vp, vp, i32, vp, _LP, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
-    "mi3d_unet_backward_loss": (i32, [_DP, vp, vp, vp, vp, vp, _LP, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp]),
+    "mi3d_head_loss_forward": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i64, _LP, vp, vp, vp, vp, vp, vp, vp]),
+    "mi3d_head_loss_backward": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mi3d_unet_forward_loss": (i32, [_DP, vp, vp, vp, vp, i32, vp, vp, _LP, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mi3d_unet_head_loss_forward": (i32, [_DP, vp, vp, vp, _LP, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mi3d_unet_backward_loss": (i32, [_DP, vp, vp, vp, vp, vp, vp, _LP, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp]),
     "mi3d_seg_metrics_workspace_bytes": (sz, [i32]),
     "mi3d_seg_metrics": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp]),
     "mi3d_seg_class_counts": (i32, [vp, vp, i32, i32, i64, vp, vp, vp]),

@@ -214,19 +214,20 @@ int mi3d_conv1_forward(int dtype, const void* z, int zcs, int Cin, const float* 
 int mi3d_head_loss_supported(int dtype, int Cin, int C, const mi3d_loss_cfg* cfg) {
     return cfg && head_loss_bwd_ok(dtype, nullptr, Cin, Cin, C, to_cfg(cfg), nullptr, Cin) ? 1 : 0;
 }
-int mi3d_head_loss_forward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
-                           int D, int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out,
-                           void* loss_workspace, void* metrics_workspace, float* logits_opt, void* stream) {
+int mi3d_head_loss_forward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels,
+                           const float* teacher, int N, int C, int D, int64_t V, const mi3d_loss_cfg* cfg, float* loss_out, float* coef,
+                           float* metrics_out, void* loss_workspace, void* metrics_workspace, float* logits_opt, void* stream) {
     MI3D_CHECK_ARG(z && w && labels && cfg && loss_out && coef && loss_workspace, "mi3d_head_loss_forward: null pointer");
-    return head_loss_fwd(z, zcs, Cin, w, bias, labels, N, C, V, to_cfg(cfg), loss_out, coef, loss_workspace, (hipStream_t)stream, D,
-                         metrics_out, metrics_workspace, logits_opt);
+    return head_loss_fwd(z, zcs, Cin, w, bias, labels, teacher, N, C, V, to_cfg(cfg), loss_out, coef, loss_workspace, (hipStream_t)stream,
+                         D, metrics_out, metrics_workspace, logits_opt);
 }
-int mi3d_head_loss_backward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
-                            int64_t V, const mi3d_loss_cfg* cfg, const float* coef, const float* grad_scale, void* dz, int dzcs,
-                            float* dW, float* db, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+int mi3d_head_loss_backward(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels,
+                            const float* teacher, int N, int C, int64_t V, const mi3d_loss_cfg* cfg, const float* coef,
+                            const float* grad_scale, void* dz, int dzcs, float* dW, float* db, int accumulate, void* workspace,
+                            size_t workspace_bytes, void* stream) {
     MI3D_CHECK_ARG(z && w && labels && cfg && coef && dz && workspace, "mi3d_head_loss_backward: null pointer");
     MI3D_CHECK_ARG(workspace_bytes >= mi3d_conv1_workspace_bytes(Cin, C), "mi3d_head_loss_backward: workspace too small");
-    return head_loss_bwd(z, zcs, Cin, w, bias, labels, C, to_cfg(cfg), coef, grad_scale, dz, dzcs, dW, db, accumulate,
+    return head_loss_bwd(z, zcs, Cin, w, bias, labels, teacher, C, to_cfg(cfg), coef, grad_scale, dz, dzcs, dW, db, accumulate,
                          (float*)workspace, N, V, (hipStream_t)stream);
 }
 int mi3d_conv1_backward(int dtype, const void* z, int zcs, int Cin, const float* w, const float* dlogits, int Cout, void* dz,

@@ -614,9 +614,10 @@ __device__ __forceinline__ void head_logits16(const bf16* __restrict__ zrow, int
 // HLW waves per workgroup: the partial rows (one per workgroup) are capped at LOSS_MAXBLK for the single-workgroup finalize, so the
 // waves a streaming pass needs to cover the memory latency come from fat workgroups (1024 threads: 32 waves per CU at 2 per CU)
 constexpr int HLW = 16;
-template <int NC, bool METRICS, bool EXACT>
+template <int NC, bool METRICS, bool EXACT, bool TEACH>
 __global__ __launch_bounds__(HLW * 64) void head_loss_fwd_kernel(const bf16* __restrict__ zin, int zcs, int Cin, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const int64_t* __restrict__ labels,
+                                                            const float* __restrict__ teacher, float inv_t,
                                                             int C_, int64_t V, double* __restrict__ part,
                                                             unsigned long long* __restrict__ counts, float* __restrict__ logits_opt) {
     const int C = EXACT ? NC : C_;
@@ -629,7 +630,8 @@ __global__ __launch_bounds__(HLW * 64) void head_loss_fwd_kernel(const bf16* __r
     int n = blockIdx.y;
     const bf16* zn = zin + (int64_t)n * V * zcs;
     const int64_t* lb = labels + (int64_t)n * V;
-    float q[2 + 2 * NC];                             // ce, (kl = 0), I[c], P[c]
+    const float* tg = TEACH ? teacher + (int64_t)n * C * V : nullptr;
+    float q[2 + 2 * NC];                             // ce, kl, I[c], P[c]
 #pragma unroll
     for (int i = 0; i < 2 + 2 * NC; i++) q[i] = 0.f;
     // every wave runs the same number of iterations (the ballots below are wave-wide): out-of-range lanes carry t = -1.
@@ -690,6 +692,19 @@ __global__ __launch_bounds__(HLW * 64) void head_loss_fwd_kernel(const bf16* __r
                 }
             }
             q[0] += live ? lse - zt : 0.f;
+            if constexpr (TEACH) {                       // the distillation term of seg_loss_fwd_kernel, teacher logits from memory
+                float ztv[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) ztv[c] = ((EXACT || c < C) && live) ? tg[(int64_t)c * V + v] : 0.f;
+                float ps[NC], pt[NC], ls, lt;
+                softmax_c<NC>(z, C, inv_t, ps, ls);
+                softmax_c<NC>(ztv, C, inv_t, pt, lt);
+                float kl = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    if ((EXACT || c < C) && pt[c] > 0.f) kl += pt[c] * ((ztv[c] * inv_t - lt) - (z[c] * inv_t - ls));
+                q[1] += live ? kl : 0.f;
+            }
             float bvv = z[0];
             int best = 0;
 #pragma unroll
@@ -752,8 +767,10 @@ __global__ __launch_bounds__(HLW * 64) void head_loss_fwd_kernel(const bf16* __r
 // re-derive voxel l's logits from that tile (head_logits16: the forward's bits), turn them into dL/dz with dlogits_voxel and
 // leave them in a wave-private [class][32 voxels] LDS tile, from which both MFMA operands are read where the plain kernel
 // reads the dlogits planes.  Cin = 16 (one input block), Cout <= 4.
+template <bool TEACH>
 __global__ __launch_bounds__(C1W * 64) void head_loss_bwd_mfma_kernel(const bf16* __restrict__ z, int zcs, const float* __restrict__ w,
                                                                       const float* __restrict__ bias, const int64_t* __restrict__ labels,
+                                                                      const float* __restrict__ teacher, float inv_t,
                                                                       int Cout, const float* __restrict__ coef,
                                                                       const float* __restrict__ grad_out, bf16* __restrict__ dz, int dzcs,
                                                                       int64_t V, float* __restrict__ slabs) {
@@ -768,11 +785,12 @@ __global__ __launch_bounds__(C1W * 64) void head_loss_bwd_mfma_kernel(const bf16
     const bf16* zn = z + (int64_t)n * V * zcs;
     bf16* dzn = dz ? dz + (int64_t)n * V * dzcs : nullptr;
     const int64_t* lb = labels + (int64_t)n * V;
+    const float* tg = TEACH ? teacher + (int64_t)n * Cout * V : nullptr;
     float go = grad_out ? grad_out[0] : 1.f;
     float A[NC], B[NC], kd0[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) { A[c] = coef[c]; B[c] = coef[MAXC + c]; kd0[c] = 0.f; }
-    float ce_s = coef[2 * MAXC];
+    float ce_s = coef[2 * MAXC], kd_s = coef[2 * MAXC + 1];
     bf16x8 aw;
 #pragma unroll
     for (int j = 0; j < 8; j++) aw[j] = (bf16)0.f;
@@ -800,6 +818,15 @@ __global__ __launch_bounds__(C1W * 64) void head_loss_bwd_mfma_kernel(const bf16
         {
             float zl[NC], o[NC];
             head_logits16<NC>(zt[wave][hl] + (lane & 31) * 16, Cin, w, bias, Cout, zl);
+            if constexpr (TEACH) {                       // the distillation term of seg_loss_bwd_kernel
+                float ztv[NC], ps[NC], pt[NC], ls, lt;
+#pragma unroll
+                for (int c = 0; c < NC; c++) ztv[c] = (c < Cout && vl < V) ? tg[(int64_t)c * V + vl] : 0.f;
+                softmax_c<NC>(zl, Cout, inv_t, ps, ls);
+                softmax_c<NC>(ztv, Cout, inv_t, pt, lt);
+#pragma unroll
+                for (int c = 0; c < NC; c++) kd0[c] = kd_s * (ps[c] - pt[c]);
+            }
             dlogits_voxel<NC>(zl, tl, Cout, A, B, ce_s, go, kd0, o);
 #pragma unroll
             for (int c = 0; c < NC; c++) dlt[wave][hl][c * 32 + (lane & 31)] = (c < Cout && vl < V) ? o[c] : 0.f;
@@ -1163,18 +1190,20 @@ int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D,
 
 // ---- head + loss fused (training step)
 bool head_loss_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg) {
-    return dtype == MI3D_BF16 && Cin % CINB == 0 && zcs % 8 == 0 && al16(z) && C >= 1 && C <= 4 && cfg.w_kd == 0.f &&
-           !getenv("MI3D_NO_HEAD_LOSS");
+    return dtype == MI3D_BF16 && Cin % CINB == 0 && zcs % 8 == 0 && al16(z) && C >= 1 && C <= 4 && !getenv("MI3D_NO_HEAD_LOSS");
 }
 bool head_loss_bwd_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg, const void* dz, int dzcs) {
     return head_loss_ok(dtype, z, zcs, Cin, C, cfg) && Cin == 16 && (!dz || (dzcs % 4 == 0 && ((uintptr_t)dz % 8) == 0)) &&
            !getenv("MI3D_NO_CONV1_MFMA");
 }
 
-int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
-                  int64_t V, LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s, int D, float* metrics_out,
+int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, const float* teacher,
+                  int N, int C, int64_t V, LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s, int D, float* metrics_out,
                   void* metrics_ws, float* logits_opt) {
     MI3D_CHECK_ARG(head_loss_ok(MI3D_BF16, z, zcs, Cin, C, cfg), "head_loss_fwd: unsupported shape Cin=%d C=%d", Cin, C);
+    MI3D_CHECK_ARG(cfg.w_kd == 0.f || teacher, "head_loss_fwd: distillation weight without teacher logits");
+    const float* tch = cfg.w_kd != 0.f ? teacher : nullptr;
+    const float it = 1.f / cfg.temp;
     MI3D_CHECK_ARG(N <= LOSS_MAXBLK, "head_loss_fwd: batch %d > %d unsupported", N, LOSS_MAXBLK);
     int64_t wantb = (V + HLW * 64 - 1) / (HLW * 64), capb = LOSS_MAXBLK / N < 1 ? 1 : LOSS_MAXBLK / N;
     int bx = (int)(wantb < capb ? wantb : capb);
@@ -1182,12 +1211,14 @@ int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* 
     bool met = metrics_out && metrics_ws;
     unsigned long long* cw = (unsigned long long*)metrics_ws;
     const bf16* zp = (const bf16*)z;
-#define HLF(ME_, EX_) head_loss_fwd_kernel<4, ME_, EX_><<<grid, HLW * 64, 0, s>>>(zp, zcs, Cin, w, bias, labels, C, V, (double*)ws, cw, logits_opt)
+#define HLF3(ME_, EX_, TE_) head_loss_fwd_kernel<4, ME_, EX_, TE_><<<grid, HLW * 64, 0, s>>>(zp, zcs, Cin, w, bias, labels, tch, it, C, V, (double*)ws, cw, logits_opt)
+#define HLF(ME_, EX_) do { if (tch) HLF3(ME_, EX_, true); else HLF3(ME_, EX_, false); } while (0)
     if (met && C == 4) HLF(true, true);
     else if (met) HLF(true, false);
     else if (C == 4) HLF(false, true);
     else HLF(false, false);
 #undef HLF
+#undef HLF3
     MI3D_LAUNCH_CHECK();
     if (met) seg_loss_metrics_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, cw, bx * N, N, C, D, V, cfg, loss_out, coef, metrics_out);
     else seg_loss_finalize_kernel<<<1, 1024, 0, s>>>((const double*)ws, bx * N, N, C, V, cfg, loss_out, coef);
@@ -1195,10 +1226,13 @@ int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* 
     return 0;
 }
 
-int head_loss_bwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int C,
+int head_loss_bwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, const float* teacher, int C,
                   LossCfg cfg, const float* coef, const float* grad_out, void* dz, int dzcs, float* dW, float* db, int accumulate,
                   float* ws, int N, int64_t V, hipStream_t s, SlabJob* pend) {
     MI3D_CHECK_ARG(head_loss_bwd_ok(MI3D_BF16, z, zcs, Cin, C, cfg, dz, dzcs), "head_loss_bwd: unsupported shape Cin=%d C=%d", Cin, C);
+    MI3D_CHECK_ARG(cfg.w_kd == 0.f || teacher, "head_loss_bwd: distillation weight without teacher logits");
+    const float* tch = cfg.w_kd != 0.f ? teacher : nullptr;
+    const float it = 1.f / cfg.temp;
     MI3D_CHECK_ARG(N <= CONV1_NBLK, "head_loss_bwd: batch %d > %d unsupported", N, CONV1_NBLK);
     int64_t nW = (int64_t)Cin * C;
     const int capb = 1024;             // as conv1_bwd's matrix-core route: same workgroup -> voxel map, same slabs
@@ -1206,7 +1240,8 @@ int head_loss_bwd(const void* z, int zcs, int Cin, const float* w, const float* 
     int bx = capb / N < 1 ? 1 : capb / N;
     if (bx > want) bx = (int)want;
     dim3 grid((unsigned)bx, (unsigned)N, 1);
-    head_loss_bwd_mfma_kernel<<<grid, C1W * 64, 0, s>>>((const bf16*)z, zcs, w, bias, labels, C, coef, grad_out, (bf16*)dz, dzcs, V, ws);
+    if (tch) head_loss_bwd_mfma_kernel<true><<<grid, C1W * 64, 0, s>>>((const bf16*)z, zcs, w, bias, labels, tch, it, C, coef, grad_out, (bf16*)dz, dzcs, V, ws);
+    else head_loss_bwd_mfma_kernel<false><<<grid, C1W * 64, 0, s>>>((const bf16*)z, zcs, w, bias, labels, nullptr, it, C, coef, grad_out, (bf16*)dz, dzcs, V, ws);
     MI3D_LAUNCH_CHECK();
     if (pend) { *pend = slab_job_make(0, ws, bx * N, nW + C, nW, dW, db, Cin, C, accumulate); return 0; }
     return slab_reduce(ws, bx * N, nW + C, nW, dW, db, accumulate, s);

@@ -204,13 +204,13 @@ int seg_loss_fwd(const float* logits, const int64_t* labels, const float* teache
 int seg_loss_bwd(const float* logits, const int64_t* labels, const float* teacher, int N, int C, int64_t V,
                  LossCfg cfg, const float* coef, const float* grad_out, float* dlogits, hipStream_t s);
 // head + loss of the training step in one pass each way (logits / dlogits never written); `*_ok` says whether the shape has
-// the fused kernels (bf16, Cin % 16 == 0, <= 4 classes, no distillation term; backward: Cin == 16)
+// the fused kernels (bf16, Cin % 16 == 0, <= 4 classes; backward: Cin == 16); teacher: (N,C,V) float logits, needed iff cfg.w_kd != 0
 bool head_loss_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg);
 bool head_loss_bwd_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg, const void* dz, int dzcs);
-int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int N, int C,
-                  int64_t V, LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s, int D, float* metrics_out,
+int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, const float* teacher,
+                  int N, int C, int64_t V, LossCfg cfg, float* loss_out, float* coef, void* ws, hipStream_t s, int D, float* metrics_out,
                   void* metrics_ws, float* logits_opt);
-int head_loss_bwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, int C,
+int head_loss_bwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, const float* teacher, int C,
                   LossCfg cfg, const float* coef, const float* grad_out, void* dz, int dzcs, float* dW, float* db, int accumulate,
                   float* ws, int N, int64_t V, hipStream_t s, SlabJob* pend = nullptr);
 size_t seg_metrics_ws_bytes(int C);

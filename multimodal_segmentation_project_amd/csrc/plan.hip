@@ -482,6 +482,7 @@ int mi3d_unet_segment_params(const mi3d_unet_desc* d, int seg, int* r) {
 struct HeadLoss {
     const int64_t* labels; LossCfg cfg; float* loss_out; float* coef; float* metrics_out; void* loss_ws; void* met_ws;   // forward
     const float* grad_scale;                                                                                              // backward
+    const float* teacher;                                                                 // (N,C,V) teacher logits iff cfg.w_kd != 0
 };
 static LossCfg cfg_of(const mi3d_loss_cfg* c) {
     LossCfg k;
@@ -495,7 +496,7 @@ static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void
                       size_t workspace_bytes, void* stream, const HeadLoss* hl) {
     Plan p;
     MI3D_TRY(build_plan(d, p));
-    MI3D_CHECK_ARG(x && params && (logits || hl) && workspace, "mi3d_unet_forward: null pointer");
+    MI3D_CHECK_ARG(x && params && workspace, "mi3d_unet_forward: null pointer");
     MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
     MI3D_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
@@ -549,21 +550,38 @@ static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void
     if (hl) {
         MI3D_CHECK_ARG(head_loss_ok(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], d->out_channels, hl->cfg),
                        "mi3d_unet_forward_loss: no fused head + loss for this configuration (see mi3d_unet_head_loss_supported)");
-        return head_loss_fwd(c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), hl->labels, d->N,
-                             d->out_channels, p.geo[0].V(), hl->cfg, hl->loss_out, hl->coef, hl->loss_ws, c.s, d->D, hl->metrics_out,
-                             hl->met_ws, logits);
+        return head_loss_fwd(c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), hl->labels, hl->teacher,
+                             d->N, d->out_channels, p.geo[0].V(), hl->cfg, hl->loss_out, hl->coef, hl->loss_ws, c.s, d->D,
+                             hl->metrics_out, hl->met_ws, logits);
     }
-    MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
-                       d->out_channels, d->N, p.geo[0].V(), c.s));
+    if (logits)       // NULL: the caller does not want the logits (DANN target pass) or runs the head with mi3d_unet_head_loss_forward
+        MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
+                           d->out_channels, d->N, p.geo[0].V(), c.s));
     return 0;
 }
 
 extern "C" {
 
+// head + loss on the decoder output the last mi3d_unet_forward / mi3d_unet_infer (logits = NULL) left in this workspace
+int mi3d_unet_head_loss_forward(const mi3d_unet_desc* d, const void* const* params, const int64_t* labels, const float* teacher_logits,
+                                const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out, void* loss_workspace,
+                                void* metrics_workspace, float* logits_opt, void* workspace, size_t workspace_bytes, void* stream) {
+    Plan p;
+    MI3D_TRY(build_plan(d, p));
+    MI3D_CHECK_ARG(params && labels && cfg && loss_out && coef && loss_workspace && workspace, "mi3d_unet_head_loss_forward: null pointer");
+    MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
+    Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
+    LossCfg k = cfg_of(cfg);
+    MI3D_CHECK_ARG(head_loss_ok(p.dt, c.at(p.zd[p.L - 1]), p.C[0], p.C[0], d->out_channels, k),
+                   "mi3d_unet_head_loss_forward: no fused head + loss for this configuration (see mi3d_unet_head_loss_supported)");
+    return head_loss_fwd(c.at(p.zd[p.L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), labels, teacher_logits, d->N,
+                         d->out_channels, p.geo[0].V(), k, loss_out, coef, loss_workspace, c.s, d->D, metrics_out, metrics_workspace,
+                         logits_opt);
+}
+
 int mi3d_unet_forward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
                       const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
                       size_t workspace_bytes, void* stream) {
-    MI3D_CHECK_ARG(logits, "mi3d_unet_forward: null pointer");
     return unet_forward_impl(d, x, params, buffers, drop_scales, training, logits, gap_out, workspace, workspace_bytes, stream, nullptr);
 }
 
@@ -576,11 +594,12 @@ int mi3d_unet_head_loss_supported(const mi3d_unet_desc* d, const mi3d_loss_cfg* 
 }
 
 int mi3d_unet_forward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
-                           const float* drop_scales, int training, const int64_t* labels, const mi3d_loss_cfg* cfg,
-                           float* loss_out, float* coef, float* metrics_out, void* loss_workspace, void* metrics_workspace,
-                           float* logits_opt, float* gap_out, void* workspace, size_t workspace_bytes, void* stream) {
+                           const float* drop_scales, int training, const int64_t* labels, const float* teacher_logits,
+                           const mi3d_loss_cfg* cfg, float* loss_out, float* coef, float* metrics_out, void* loss_workspace,
+                           void* metrics_workspace, float* logits_opt, float* gap_out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
     MI3D_CHECK_ARG(labels && cfg && loss_out && coef && loss_workspace, "mi3d_unet_forward_loss: null pointer");
-    HeadLoss hl{labels, cfg_of(cfg), loss_out, coef, metrics_out, loss_workspace, metrics_workspace, nullptr};
+    HeadLoss hl{labels, cfg_of(cfg), loss_out, coef, metrics_out, loss_workspace, metrics_workspace, nullptr, teacher_logits};
     return unet_forward_impl(d, x, params, buffers, drop_scales, training, logits_opt, gap_out, workspace, workspace_bytes, stream, &hl);
 }
 
@@ -604,7 +623,7 @@ int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* 
                     float* logits, float* gap_out, void* workspace, size_t workspace_bytes, void* stream) {
     Plan p;
     MI3D_TRY(build_plan(d, p));
-    MI3D_CHECK_ARG(x && params && buffers && logits && workspace, "mi3d_unet_infer: null pointer");
+    MI3D_CHECK_ARG(x && params && buffers && workspace, "mi3d_unet_infer: null pointer");
     MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
     MI3D_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
@@ -658,8 +677,9 @@ int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* 
             MI3D_TRY(nearest_resize_fwd(p.dt, udst, udcs, p.C[l], p.up_geo(l), catl + p.half_off(l), p.catcs(l), p.geo[l], c.s));
         MI3D_TRY(block_infer(c, L + 1 + i, x));
     }
-    MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
-                       d->out_channels, d->N, p.geo[0].V(), c.s));
+    if (logits)
+        MI3D_TRY(conv1_fwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), logits,
+                           d->out_channels, d->N, p.geo[0].V(), c.s));
     return 0;
 }
 
@@ -691,7 +711,7 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
                 MI3D_CHECK_ARG(head_loss_bwd_ok(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], d->out_channels, hl->cfg, c.at(p.gz[0]), p.C[0]),
                                "mi3d_unet_backward_loss: no fused head + loss for this configuration (see mi3d_unet_head_loss_supported)");
                 MI3D_TRY(head_loss_bwd(c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), c.P(p.final_pidx() + 1), hl->labels,
-                                       d->out_channels, hl->cfg, hl->coef, hl->grad_scale, c.at(p.gz[0]), p.C[0], G(p.final_pidx()),
+                                       hl->teacher, d->out_channels, hl->cfg, hl->coef, hl->grad_scale, c.at(p.gz[0]), p.C[0], G(p.final_pidx()),
                                        G(p.final_pidx() + 1), accumulate, wgws, d->N, p.geo[0].V(), c.s, ps));
             } else
                 MI3D_TRY(conv1_bwd(p.dt, c.at(p.zd[L - 1]), p.C[0], p.C[0], c.P(p.final_pidx()), dlogits, d->out_channels,
@@ -764,11 +784,11 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
 }
 
 int mi3d_unet_backward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
-                            const float* drop_scales, const int64_t* labels, const mi3d_loss_cfg* cfg, const float* coef,
-                            const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin, int seg_end,
-                            void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events) {
+                            const float* drop_scales, const int64_t* labels, const float* teacher_logits, const mi3d_loss_cfg* cfg,
+                            const float* coef, const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin,
+                            int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events) {
     MI3D_CHECK_ARG(labels && cfg && coef, "mi3d_unet_backward_loss: null pointer");
-    HeadLoss hl{labels, cfg_of(cfg), nullptr, const_cast<float*>(coef), nullptr, nullptr, nullptr, grad_scale};
+    HeadLoss hl{labels, cfg_of(cfg), nullptr, const_cast<float*>(coef), nullptr, nullptr, nullptr, grad_scale, teacher_logits};
     return unet_backward_impl(d, x, params, grads, drop_scales, nullptr, dgap, gap_scale, accumulate, seg_begin, seg_end, workspace,
                               workspace_bytes, stream, aux_stream, events, &hl);
 }

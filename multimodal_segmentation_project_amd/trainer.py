@@ -406,7 +406,7 @@ class TrainStep(_StepBase):
         st["btab"] = ptr_table([b.data_ptr() for b in self.model.buffers()])
         if mode == "train":
             st["dlogits"] = torch.empty_like(st["logits"])
-            st["fused_head"] = (self.teacher is None and not os.environ.get("MI3D_NO_HEAD_LOSS") and
+            st["fused_head"] = (not os.environ.get("MI3D_NO_HEAD_LOSS") and
                                 lib.mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.cfg)) == 1)
             st["ndrop"] = lib.mi3d_unet_dropout_count(C.byref(desc))
             st["drop"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
@@ -475,11 +475,16 @@ class TrainStep(_StepBase):
                      ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], ks.cuda_stream)
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
         fused = st["fused_head"]
-        if fused:
+        keep = ptr(st["logits"]) if self.keep_logits else None
+        if fused and self.teacher is None:
             # 1x1x1 head + loss + metrics in one pass: the logits are never written (mi3d.h, mi3d_unet_forward_loss)
-            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1, ptr(st["y"]),
+            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1, ptr(st["y"]), None,
                  C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
-                 ptr(st["met_ws"]), ptr(st["logits"]) if self.keep_logits else None, None, ptr(st["ws"]), st["ws_bytes"], s)
+                 ptr(st["met_ws"]), keep, None, ptr(st["ws"]), st["ws_bytes"], s)
+        elif fused:
+            # distillation: the student's body now, its head + loss after the join with the teacher's stream (below)
+            call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1,
+                 None, None, ptr(st["ws"]), st["ws_bytes"], s)
         else:
             call("mi3d_unet_forward", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1,
                  ptr(st["logits"]), None, ptr(st["ws"]), st["ws_bytes"], s)
@@ -491,6 +496,10 @@ class TrainStep(_StepBase):
                 call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["t_ptab"], st["t_btab"],
                      ptr(st["t_logits"]), None, ptr(st["t_ws"]), st["ws_bytes"], s)
             t_logits = st["t_logits"]
+        if fused and self.teacher is not None:
+            call("mi3d_unet_head_loss_forward", C.byref(desc), st["ptab"], ptr(st["y"]), ptr(t_logits), C.byref(self.cfg),
+                 ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]), ptr(st["met_ws"]), keep,
+                 ptr(st["ws"]), st["ws_bytes"], s)
         # loss + metrics (SURVEY Q1 loop bound D) of the same logits in one pass (replaces 3 argmaxes + 2(D-1) host syncs)
         if not fused:
             call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, desc.D, v,
@@ -523,8 +532,8 @@ class TrainStep(_StepBase):
                         call("mi3d_set_cu_budget", budget)
                     if fused:
                         call("mi3d_unet_backward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
-                             ptr(st["y"]), C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), None, 1.0, accumulate, start,
-                             seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux, self._events)
+                             ptr(st["y"]), ptr(t_logits), C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), None, 1.0,
+                             accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux, self._events)
                     else:
                         call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
                              ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
@@ -591,11 +600,20 @@ class TrainStep(_StepBase):
         desc = st["desc"]
         s = stream_ptr()
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
-        call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(st["logits"]), None,
-             ptr(st["ws"]), st["ws_bytes"], s)
-        call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
-             C.byref(self.eval_cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
-             ptr(st["met_ws"]), s)
+        fused = (not os.environ.get("MI3D_NO_HEAD_LOSS") and not self.keep_logits and
+                 _lib.lib().mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.eval_cfg)) == 1)
+        if fused:       # head + loss + metrics on the decoder output: the validation logits are never written either
+            call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], None, None,
+                 ptr(st["ws"]), st["ws_bytes"], s)
+            call("mi3d_unet_head_loss_forward", C.byref(desc), st["ptab"], ptr(st["y"]), None, C.byref(self.eval_cfg),
+                 ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]), ptr(st["met_ws"]), None,
+                 ptr(st["ws"]), st["ws_bytes"], s)
+        else:
+            call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(st["logits"]), None,
+                 ptr(st["ws"]), st["ws_bytes"], s)
+            call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
+                 C.byref(self.eval_cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
+                 ptr(st["met_ws"]), s)
         out = st["metrics"].clone()
         self.comm.average_(out)
         return out
@@ -690,7 +708,6 @@ class DannStep(_StepBase):
         st["xt"] = torch.empty(tuple(xs.shape), dtype=torch.float32, device=dev)
         st["y"] = torch.empty((n, desc.D * desc.H * desc.W), dtype=torch.int64, device=dev)
         st["logits"] = torch.empty((n, c, desc.D, desc.H, desc.W), dtype=torch.float32, device=dev)
-        st["logits_t"] = torch.empty_like(st["logits"])
         st["dlogits"] = torch.empty_like(st["logits"])
         st["fused_head"] = (not os.environ.get("MI3D_NO_HEAD_LOSS") and
                             lib.mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.cfg)) == 1)
@@ -757,10 +774,10 @@ class DannStep(_StepBase):
             fs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(fs):
                 call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab_side"], ptr(drop_t), 2,
-                     ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], fs.cuda_stream)
+                     None, feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], fs.cuda_stream)
         fused = st["fused_head"]
         if fused:       # source head + loss + metrics in one pass, logits never written (mi3d_unet_forward_loss)
-            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1, ptr(st["y"]),
+            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1, ptr(st["y"]), None,
                  C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
                  ptr(st["met_ws"]), None, feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
         else:
@@ -771,7 +788,7 @@ class DannStep(_StepBase):
             call("mi3d_unet_bn_apply_deferred", C.byref(desc), st["btab"], st["btab_side"], s)
         else:
             call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab"], ptr(drop_t), 1,
-                 ptr(st["logits_t"]), feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], s)
+                 None, feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], s)      # the target logits are never read
         if not fused:
             call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,
                  C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
@@ -824,7 +841,7 @@ class DannStep(_StepBase):
             if last or exch:
                 if fused:
                     call("mi3d_unet_backward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s), ptr(st["y"]),
-                         C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), dgs, -lam, accumulate, start, sg + 1,
+                         None, C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), dgs, -lam, accumulate, start, sg + 1,
                          ptr(st["ws_s"]), st["ws_bytes"], s, None, None)
                 else:
                     call("mi3d_unet_backward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s),

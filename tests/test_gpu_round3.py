@@ -300,9 +300,7 @@ def test_two_stream_forwards_are_bitwise_the_serial_order():
         seg = unet_dann.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
         torch.manual_seed(3)
         disc = DomainDiscriminator(256).to(DEV).train()
-        for mod in disc.modules():
-            if isinstance(mod, torch.nn.Dropout):
-                mod.p = 0.0
+        disc._mi3d_injected_drop_scales = [torch.ones(4, 256, device=DEV), torch.ones(4, 128, device=DEV)]      # no discriminator dropout
         ts = DannStep(seg, disc, loss="combined", lambda_domain=0.2, compute_dtype=torch.bfloat16, use_graph=graph,
                       overlap_forwards=overlap)
         mets = [ts.step(xs.to(DEV), ys.to(DEV), xt.to(DEV)).clone() for _ in range(3)]
@@ -363,23 +361,25 @@ def test_eight_wave_conv_is_bit_identical_to_the_four_wave_kernel(monkeypatch):
 
 # ------------------------------------------------------------------------------------------------ head + loss in one pass
 @pytest.mark.parametrize("case", [(2, 4, 16, 16, 16, "combined"), (1, 4, 5, 7, 9, "ce_tversky"), (2, 3, 4, 6, 50, "combined"),
-                                  (3, 2, 3, 5, 37, "dice")])
+                                  (3, 2, 3, 5, 37, "dice"), (2, 4, 8, 12, 20, "kd"), (1, 3, 5, 6, 11, "kd")])
 def test_head_loss_fused_passes_against_the_unfused_operators(case):
     """mi3d_head_loss_forward / _backward (the training step's 1x1x1 head folded into the loss, models/unet.py:62,87 +
     utils/metrics.py:14-40) against the operator chain they replace: mi3d_conv1_forward -> mi3d_seg_loss_metrics_forward and
     mi3d_seg_loss_backward -> mi3d_conv1_backward.  The kept logits are the unfused head's bit for bit; the metrics come from
     integer counts (exact); the loss sums the same per-voxel terms in another order (a few ulp); given the SAME coefficients the
-    fused backward is bitwise the unfused pair.  Ragged voxel counts and C < 4 included."""
+    fused backward is bitwise the unfused pair.  Ragged voxel counts, C < 4 and the distillation term (teacher logits from
+    memory, distill_unet.py:107-115) included."""
     from multimodal_segmentation_project_amd.trainer import _loss_cfg
     n, c, d, h, w, loss = case
     cin, v = 16, d * h * w
-    cfg = _loss_cfg(loss)
+    cfg = _loss_cfg("combined", 0.7, 2.0) if loss == "kd" else _loss_cfg(loss)
     assert _lib.lib().mi3d_head_loss_supported(1, cin, c, C.byref(cfg)) == 1
     g = torch.Generator().manual_seed(v + c)
     z = (torch.randn(n, v, cin, generator=g) * 1.5).bfloat16().to(DEV)
     wgt = (torch.randn(c, cin, generator=g) * 0.4).to(DEV)
     bias = (torch.randn(c, generator=g) * 0.2).to(DEV)
     lab = torch.randint(0, c, (n, v), generator=g).to(DEV)
+    teach = (torch.randn(n, c, v, generator=g) * 1.2).to(DEV) if loss == "kd" else None
     lib = _lib.lib()
     lws = torch.empty(lib.mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=DEV)
     mws = torch.empty(lib.mi3d_seg_metrics_workspace_bytes(c), dtype=torch.uint8, device=DEV)
@@ -390,32 +390,32 @@ def test_head_loss_fused_passes_against_the_unfused_operators(case):
     logits = torch.empty((n, c, v), device=DEV)
     call("mi3d_conv1_forward", 1, ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(logits), c, n, v, None)
     met0, coef0 = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
-    call("mi3d_seg_loss_metrics_forward", ptr(logits), ptr(lab), None, n, c, d, v, C.byref(cfg), ptr(met0), ptr(coef0), ptr(met0[1:]),
+    call("mi3d_seg_loss_metrics_forward", ptr(logits), ptr(lab), ptr(teach), n, c, d, v, C.byref(cfg), ptr(met0), ptr(coef0), ptr(met0[1:]),
          ptr(lws), ptr(mws), None)
     dl = torch.empty_like(logits)
-    call("mi3d_seg_loss_backward", ptr(logits), ptr(lab), None, n, c, v, C.byref(cfg), ptr(coef0), ptr(scale), ptr(dl), None)
+    call("mi3d_seg_loss_backward", ptr(logits), ptr(lab), ptr(teach), n, c, v, C.byref(cfg), ptr(coef0), ptr(scale), ptr(dl), None)
     dz0 = torch.empty_like(z)
     dW0, db0 = torch.empty((c, cin), device=DEV), torch.empty(c, device=DEV)
     call("mi3d_conv1_backward", 1, ptr(z), cin, cin, ptr(wgt), ptr(dl), c, ptr(dz0), cin, ptr(dW0), ptr(db0), 0, n, v, ptr(ws), wsb, None)
     # fused
     met1, coef1 = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
     kept = torch.empty_like(logits)
-    call("mi3d_head_loss_forward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), n, c, d, v, C.byref(cfg), ptr(met1), ptr(coef1),
-         ptr(met1[1:]), ptr(lws), ptr(mws), ptr(kept), None)
+    call("mi3d_head_loss_forward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), ptr(teach), n, c, d, v, C.byref(cfg), ptr(met1),
+         ptr(coef1), ptr(met1[1:]), ptr(lws), ptr(mws), ptr(kept), None)
     assert torch.equal(kept, logits)
     assert torch.equal(met1[1:], met0[1:])                                  # iou / dice / acc: from exact counts
     assert abs(float(met1[0]) - float(met0[0])) <= 2e-6 * abs(float(met0[0]))
     np.testing.assert_allclose(coef1.cpu().numpy(), coef0.cpu().numpy(), rtol=2e-6, atol=1e-12)
     dz1 = torch.empty_like(z)
     dW1, db1 = torch.empty((c, cin), device=DEV), torch.empty(c, device=DEV)
-    call("mi3d_head_loss_backward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), n, c, v, C.byref(cfg), ptr(coef0), ptr(scale),
-         ptr(dz1), cin, ptr(dW1), ptr(db1), 0, ptr(ws), wsb, None)
+    call("mi3d_head_loss_backward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), ptr(teach), n, c, v, C.byref(cfg), ptr(coef0),
+         ptr(scale), ptr(dz1), cin, ptr(dW1), ptr(db1), 0, ptr(ws), wsb, None)
     assert torch.equal(dz1.view(torch.int16), dz0.view(torch.int16))
     assert torch.equal(dW1, dW0) and torch.equal(db1, db0)
     # without the optional logits copy the results do not change
     met2, coef2 = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
-    call("mi3d_head_loss_forward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), n, c, d, v, C.byref(cfg), ptr(met2), ptr(coef2),
-         ptr(met2[1:]), ptr(lws), ptr(mws), None, None)
+    call("mi3d_head_loss_forward", ptr(z), cin, cin, ptr(wgt), ptr(bias), ptr(lab), ptr(teach), n, c, d, v, C.byref(cfg), ptr(met2),
+         ptr(coef2), ptr(met2[1:]), ptr(lws), ptr(mws), None, None)
     assert torch.equal(met2, met1) and torch.equal(coef2, coef1)
 
 
@@ -449,7 +449,7 @@ def test_train_step_with_fused_head_equals_the_unfused_step(monkeypatch):
 
 
 def test_fused_head_is_refused_where_it_has_no_kernels():
-    """fp32 activations, a distillation term or > 4 classes have no fused head + loss kernels: mi3d_unet_head_loss_supported says
+    """fp32 activations, > 4 classes or features[0] != 16 have no fused head + loss kernels: mi3d_unet_head_loss_supported says
     so, the fused entry points fail loudly (no silent fallback inside the library), and TrainStep takes the four-call sequence."""
     from multimodal_segmentation_project_amd.trainer import TrainStep, _loss_cfg
     from multimodal_segmentation_project_amd._lib import Mi3dError
@@ -460,15 +460,18 @@ def test_fused_head_is_refused_where_it_has_no_kernels():
     assert lib.mi3d_head_loss_supported(1, 16, 5, C.byref(cfg)) == 0          # 5 classes
     assert lib.mi3d_head_loss_supported(1, 32, 4, C.byref(cfg)) == 0          # backward needs features[0] == 16
     kd = _loss_cfg("combined", 0.7, 2.0)
-    assert lib.mi3d_head_loss_supported(1, 16, 4, C.byref(kd)) == 0           # distillation term
+    assert lib.mi3d_head_loss_supported(1, 16, 4, C.byref(kd)) == 1           # distillation term: supported, needs teacher logits
     z = torch.zeros((1, 64, 16), dtype=torch.bfloat16, device=DEV)
     w, b = torch.zeros((5, 16), device=DEV), torch.zeros(5, device=DEV)
     lab = torch.zeros((1, 64), dtype=torch.int64, device=DEV)
     out, coef = torch.zeros(4, device=DEV), torch.zeros(_lib.LOSS_COEF_FLOATS, device=DEV)
     lws = torch.empty(lib.mi3d_seg_loss_workspace_bytes(5), dtype=torch.uint8, device=DEV)
     with pytest.raises(Mi3dError):
-        call("mi3d_head_loss_forward", ptr(z), 16, 16, ptr(w), ptr(b), ptr(lab), 1, 5, 4, 64, C.byref(cfg), ptr(out), ptr(coef), None,
-             ptr(lws), None, None, None)
+        call("mi3d_head_loss_forward", ptr(z), 16, 16, ptr(w), ptr(b), ptr(lab), None, 1, 5, 4, 64, C.byref(cfg), ptr(out), ptr(coef),
+             None, ptr(lws), None, None, None)
+    with pytest.raises(Mi3dError):       # distillation weight without teacher logits
+        call("mi3d_head_loss_forward", ptr(z), 16, 16, ptr(w[:4]), ptr(b[:4]), ptr(lab), None, 1, 4, 4, 64, C.byref(kd), ptr(out),
+             ptr(coef), None, ptr(lws), None, None, None)
     torch.manual_seed(0)
     m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
     ts = TrainStep(m, lr=1e-3, compute_dtype=torch.float32)
@@ -477,3 +480,56 @@ def test_fused_head_is_refused_where_it_has_no_kernels():
     o = ts.step(x.to(DEV), y.to(DEV))
     assert torch.isfinite(o).all()
     ts.close()
+
+
+def test_distillation_and_dann_steps_with_fused_head_equal_the_unfused_steps(monkeypatch):
+    """TrainStep with a teacher (64^3, the student's body -> join with the teacher's stream -> head + loss with the distillation
+    term in one pass) and DannStep (48^3, source head folded into the loss, target head not run at all) against
+    MI3D_NO_HEAD_LOSS=1: metrics identical, loss to a few ulp, gradients within the noise of one ulp of `coef`."""
+    from multimodal_segmentation_project_amd.trainer import TrainStep, DannStep
+    from multimodal_segmentation_project_amd import unet_dann, dann
+    x, y = _synth(2, 64, 5)
+    res = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("MI3D_NO_HEAD_LOSS", "1")
+        torch.manual_seed(3)
+        student = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+        torch.manual_seed(4)
+        teacher = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).eval()
+        ts = TrainStep(student, lr=1e-3, weight_decay=0.0, kd_teacher=teacher, compute_dtype=torch.bfloat16)
+        assert ts._prepare(x.to(DEV))["fused_head"] == fused
+        out = ts.step(x.to(DEV), y.to(DEV)).cpu()
+        res.append((out, {k: p.grad.detach().clone().cpu() for k, p in student.named_parameters()}))
+        ts.close()
+        monkeypatch.delenv("MI3D_NO_HEAD_LOSS", raising=False)
+    (o1, g1), (o0, g0) = res
+    assert torch.equal(o1[1:], o0[1:]) and abs(float(o1[0]) - float(o0[0])) <= 2e-6 * abs(float(o0[0]))
+    worst = max(relerr(g1[k], g0[k]) for k in g0 if float(g0[k].double().norm()) > 1e-7 and
+                not (k.endswith("double_conv.0.bias") or k.endswith("double_conv.4.bias")))
+    print("distillation, fused head vs unfused: worst per-tensor gradient relerr", worst)
+    assert worst < 1e-3
+    xs, ys = _synth(2, 48, 6)
+    xt, _ = _synth(2, 48, 7)
+    res = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("MI3D_NO_HEAD_LOSS", "1")
+        torch.manual_seed(3)
+        seg = unet_dann.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+        torch.manual_seed(5)
+        disc = dann.DomainDiscriminator(256).to(DEV).train()
+        for mod in disc.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        ds = DannStep(seg, disc, lr=1e-3, weight_decay=0.0, compute_dtype=torch.bfloat16)
+        out = ds.step(xs.to(DEV), ys.to(DEV), xt.to(DEV)).cpu()
+        res.append((out, {k: p.grad.detach().clone().cpu() for k, p in seg.named_parameters()}))
+        ds.close()
+        monkeypatch.delenv("MI3D_NO_HEAD_LOSS", raising=False)
+    (o1, g1), (o0, g0) = res
+    assert torch.equal(o1[1:4], o0[1:4]) and abs(float(o1[0]) - float(o0[0])) <= 2e-6 * abs(float(o0[0]))
+    worst = max(relerr(g1[k], g0[k]) for k in g0 if float(g0[k].double().norm()) > 1e-7 and
+                not (k.endswith("double_conv.0.bias") or k.endswith("double_conv.4.bias")))
+    print("DANN, fused head vs unfused: worst per-tensor gradient relerr", worst)
+    assert worst < 1e-3
