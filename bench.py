@@ -173,6 +173,50 @@ def roofline_dominant(size, batch, dtype_code, iters=10, ts=None):
             "flops_per_launch": 2 * 2 * 27 * cin * cout * vox}
 
 
+class _SclkSampler:
+    """Shader clock during the timed region: every 20 ms the current level ('*') of every card's pp_dpm_sclk; the busiest card
+    (highest mean) is ours on a shared host.  Host-side file reads only: the step is a graph replay and does not wait on the host."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples = [[] for _ in self.files]
+        self._stop = threading.Event()
+        self._thr = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, f):
+        try:
+            for line in open(f):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            for i, f in enumerate(self.files):
+                v = self._read(f)
+                if v is not None:
+                    self.samples[i].append(v)
+            self._stop.wait(0.02)
+
+    def start(self):
+        if self.files:
+            self._thr.start()
+
+    def stop(self):
+        if not self.files:
+            return None
+        self._stop.set()
+        self._thr.join(timeout=1.0)
+        best = max((s for s in self.samples if s), key=lambda s: sum(s) / len(s), default=None)
+        if not best:
+            return None
+        return {"mean": round(sum(best) / len(best), 1), "min": min(best), "max": max(best), "samples": len(best)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +230,9 @@ def main():
     ap.add_argument("--two-stream", action="store_true", help="weight gradients on a second stream beside the data-gradient chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sclk", action="store_true",
+                    help="sample the shader clock (sysfs pp_dpm_sclk of the busiest card) during the timed steps -> \"sclk_mhz\" in the JSON "
+                         "line: boxes and builds differ in clock, an A/B should say so")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3 --pmc passes)")
     ap.add_argument("--graph-segments", action="store_true", help="world > 1 / --force-comm: replay one hipGraph per comm-free run of kernels")
     ap.add_argument("--force-comm", action="store_true",
@@ -253,9 +300,12 @@ def main():
 
     for _ in range(a.warmup):
         ts.step_static()
+    sclk = _SclkSampler() if (a.sclk and rank == 0) else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if sclk:
+        sclk.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = ts.step_static()
@@ -263,6 +313,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sclk_mhz = sclk.stop() if sclk else None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -287,6 +338,7 @@ def main():
             "final_step": {"loss": met[0], "iou": met[1], "dice": met[2], "acc": met[3]},
             "step_hbm_frac": algo_gb_step / (ms * 1e-3) / HBM_PEAK_GBS,
             "step_algorithmic_gb": algo_gb_step,
+            **({"sclk_mhz": sclk_mhz} if sclk_mhz else {}),
         }
         if not a.no_roofline:
             res["roofline"] = roofline_dominant(a.size, a.batch, 1 if a.dtype == "bf16" else 0,

@@ -33,18 +33,22 @@ def main():
         env = dict(e.split("=", 1) for e in envs.split(",") if e)
         cfgs.append((name, env))
     wall = {n: [] for n, _ in cfgs}
+    clk = {}
     for _ in range(rounds):
         for n, env in cfgs:
             e = dict(os.environ, **env)
-            out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-roofline", "--steps", str(steps)] + extra,
+            out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-roofline", "--sclk", "--steps", str(steps)] + extra,
                                  cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
             try:
-                wall[n].append(json.loads(out.stdout.strip().splitlines()[-1])["ms_per_step"])
+                line = json.loads(out.stdout.strip().splitlines()[-1])
+                wall[n].append(line["ms_per_step"])
+                clk.setdefault(n, []).append((line.get("sclk_mhz") or {}).get("mean"))
             except Exception:      # noqa: BLE001
                 print(n, "bench failed:", out.stderr[-400:])
                 wall[n].append(float("nan"))
     for n, _ in cfgs:
-        print(f"wall {n:12s} " + "  ".join(f"{v:.4f}" for v in wall[n]) + " ms/step", flush=True)
+        print(f"wall {n:12s} " + "  ".join(f"{v:.4f}" for v in wall[n]) + " ms/step" +
+              "   sclk " + " ".join(f"{c:.0f}" if c else "-" for c in clk.get(n, [])) + " MHz", flush=True)
     if "--noprof" in sys.argv:
         return
     per = {}
