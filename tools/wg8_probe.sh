@@ -1,5 +1,6 @@
 #!/bin/bash
-# eight-wave weight gradient: exactness through the stand-alone route, then per-kernel time against the four-wave kernel
+# eight-wave weight gradient: exactness through the stand-alone route, then per-kernel time against the four-wave kernel.
+# Needs profiles/r03_exp_wgrad8.patch applied (the experiment was not kept; MI3D_WGRAD8 exists only in that patch).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/wg8; rm -rf $o; mkdir -p $o
