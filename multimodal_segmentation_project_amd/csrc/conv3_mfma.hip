@@ -165,15 +165,17 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
     constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
     static_assert(TZ == 4, "one z-slice of the tile per wave");
     constexpr int MB = TYB * TXB;                  // M-blocks per wave (wave w owns z-slice w of the tile)
-    constexpr int NVOX = IZ * IY * IX;
+    // LDS row pitch: 12 voxels instead of 10 for the 4 x 4-voxel M-blocks (bank conflicts, see conv3_mfma8_kernel)
+    constexpr int IXP = BX == 4 ? 12 : IX;
+    constexpr int NVOX = IZ * IY * IX, NVOXP = IZ * IY * IXP;
     // EXT_LDS: the tile lives in the caller's (dynamic) LDS block -- a fused launch shares one block between the bodies
     bf16* xs;
     float (*red)[COB][16][2];
     if constexpr (EXT_LDS) {
         xs = reinterpret_cast<bf16*>(ext_lds);
-        red = reinterpret_cast<float (*)[COB][16][2]>(ext_lds + NVOX * 32);
+        red = reinterpret_cast<float (*)[COB][16][2]>(ext_lds + NVOXP * 32);
     } else {
-        __shared__ __attribute__((aligned(16))) bf16 xs_s[NVOX * 16];
+        __shared__ __attribute__((aligned(16))) bf16 xs_s[NVOXP * 16];
         __shared__ float red_s[4][COB][16][2];
         xs = xs_s;
         red = red_s;
@@ -192,7 +194,7 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int vn = lane & 15, g = lane >> 4;
     // per-lane LDS byte offset of its voxel inside an M-block + channel half
-    int laneOff = (((vn / BX) * IX + (vn % BX)) * 16 + (g & 1) * 8) * 2 + wave * (IY * IX * 32);
+    int laneOff = (((vn / BX) * IXP + (vn % BX)) * 16 + (g & 1) * 8) * 2 + wave * (IY * IXP * 32);
     const char* xsb = reinterpret_cast<const char*>(xs);
 
     f32x4 acc[MB][COB];
@@ -204,12 +206,13 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
     // staging map: each thread moves NIT 16-byte pieces (voxel, channel half) per chunk; the voxel -> global offset map
     // is chunk-invariant, so it is computed once (-1 = outside the volume -> zero fill)
     constexpr int NIT = (NVOX * 2 + BLK - 1) / BLK;
-    int soff[NIT];
+    int soff[NIT], sdst[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         int idx = threadIdx.x + it * BLK;
         int vox = idx >> 1, half = idx & 1;
         int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+        sdst[it] = IXP == IX ? 0 : (t * IXP + ix) * 16 + half * 8;                 // element offset of the piece in the (padded) LDS tile
         int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
         bool inb = idx < NVOX * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
         soff[it] = inb ? ((gz * H + gy) * W + gx) * xcs + half * 8 : -1;
@@ -244,7 +247,7 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             int idx = threadIdx.x + it * BLK;
-            if (idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = sv[it];
+            if (idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + (IXP == IX ? idx * 8 : sdst[it])) = sv[it];
         }
         __syncthreads();
         // async-stage split: the next chunk's global loads are in flight while this chunk's MFMAs run
@@ -259,11 +262,11 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
         constexpr int SUBS = MB / FG, NSUB = 14 * SUBS;
         auto frag_off = [&](int s) {
             int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
-            int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IX + (t0 % 3)) * 32;
-            int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IX + (t1 % 3)) * 32;
+            int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IXP + (t0 % 3)) * 32;
+            int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IXP + (t1 % 3)) * 32;
             return laneOff + ((g >> 1) ? off1 : off0);
         };
-        auto row_off = [&](int r) { return (((r / TXB) * BY) * IX + (r % TXB) * BX) * 32; };
+        auto row_off = [&](int r) { return (((r / TXB) * BY) * IXP + (r % TXB) * BX) * 32; };
         bf16x8 xf[2][FG];
         {
             int toff = frag_off(0);
@@ -388,14 +391,18 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
     constexpr int BY = 16 / BX;
     constexpr int TY = TYB * BY, TX = TXB * BX;
     constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
+    // LDS row pitch in voxels.  With 4 x 4-voxel M-blocks (BX = 4) a 10-voxel pitch puts rows 0 and 3 of a block on the same
+    // banks of a ds_read_b128 lane group (SQ_LDS_BANK_CONFLICT 24-29 % of the LDS-active cycles of these kernels); 12 voxels
+    // (384 B = 128 mod 256) makes the 16 pieces of every lane group tile the 256-byte bank row exactly
+    constexpr int IXP = BX == 4 ? 12 : IX;
     static_assert(TZ == 4, "one z-slice of the tile per wave pair");
     constexpr int MB = TYB * TXB, MBW = MB / 2;          // M-blocks per slice / per wave
     static_assert(MB % 2 == 0 && MBW <= 4, "two waves share a slice");
-    constexpr int NVOX = IZ * IY * IX;
+    constexpr int NVOX = IZ * IY * IX, NVOXP = IZ * IY * IXP;
     extern __shared__ __attribute__((aligned(16))) char lds8[];
     bf16* xs = reinterpret_cast<bf16*>(lds8);
-    bf16* wl = xs + NVOX * 16;                                   // [14][COB][64 lanes][8] of the current chunk
-    float (*red)[COB][16][2] = reinterpret_cast<float (*)[COB][16][2]>(lds8 + (NVOX * 16 + 14 * COB * 512) * 2);
+    bf16* wl = xs + NVOXP * 16;                                   // [14][COB][64 lanes][8] of the current chunk
+    float (*red)[COB][16][2] = reinterpret_cast<float (*)[COB][16][2]>(lds8 + (NVOXP * 16 + 14 * COB * 512) * 2);
     Bid bid_ = real_bid();
     int tile = xcd_contig(bid_.x, bid_.gx);
     int tx_ = tile % tilesX; tile /= tilesX;
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int zs = wave & 3, hb = wave >> 2;
     int vn = lane & 15, g = lane >> 4;
-    int laneOff = (((vn / BX) * IX + (vn % BX)) * 16 + (g & 1) * 8) * 2 + zs * (IY * IX * 32);
+    int laneOff = (((vn / BX) * IXP + (vn % BX)) * 16 + (g & 1) * 8) * 2 + zs * (IY * IXP * 32);
     const char* xsb = reinterpret_cast<const char*>(xs);
     f32x4 acc[MBW][COB];
 #pragma unroll
@@ -415,12 +422,13 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
 #pragma unroll
         for (int c = 0; c < COB; c++) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int NIT = (NVOX * 2 + NT - 1) / NT;
-    int soff[NIT];
+    int soff[NIT], sdst[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         int idx = threadIdx.x + it * NT;
         int vox = idx >> 1, half = idx & 1;
         int ix = vox % IX, t = vox / IX, iy = t % IY, iz = t / IY;
+        sdst[it] = IXP == IX ? 0 : (t * IXP + ix) * 16 + half * 8;              // element offset of the piece in the (padded) LDS tile
         int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
         bool inb = idx < NVOX * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
         soff[it] = inb ? ((gz * H + gy) * W + gx) * xcs + half * 8 : -1;
@@ -453,17 +461,17 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
     load_chunk(chunk0);
     auto frag_off = [&](int s) {
         int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
-        int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IX + (t0 % 3)) * 32;
-        int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IX + (t1 % 3)) * 32;
+        int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IXP + (t0 % 3)) * 32;
+        int off1 = (((t1 / 9) * IY + ((t1 / 3) % 3)) * IXP + (t1 % 3)) * 32;
         return laneOff + ((g >> 1) ? off1 : off0);
     };
-    auto row_off = [&](int r) { int rg = hb * MBW + r; return (((rg / TXB) * BY) * IX + (rg % TXB) * BX) * 32; };
+    auto row_off = [&](int r) { int rg = hb * MBW + r; return (((rg / TXB) * BY) * IXP + (rg % TXB) * BX) * 32; };
     for (int chunk = chunk0; chunk < nchunk; chunk++) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             int idx = threadIdx.x + it * NT;
-            if (idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + idx * 8) = sv[it];
+            if (idx < NVOX * 2) *reinterpret_cast<bf16x8*>(xs + (IXP == IX ? idx * 8 : sdst[it])) = sv[it];
         }
 #pragma unroll
         for (int i = 0; i < NWI; i++) {
@@ -556,7 +564,9 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
         }
     }
 }
-constexpr size_t conv8_lds(int TY, int TX, int COB) { return (size_t)6 * (TY + 2) * (TX + 2) * 32 + (size_t)14 * COB * 1024 + (size_t)8 * COB * 16 * 2 * 4; }
+constexpr size_t conv8_lds(int TY, int TX, int COB) {        // TX == 8 <=> BX == 4 tilings: LDS row pitch 12 voxels (see the kernel)
+    return (size_t)6 * (TY + 2) * (TX == 8 ? 12 : TX + 2) * 32 + (size_t)14 * COB * 1024 + (size_t)8 * COB * 16 * 2 * 4;
+}
 
 // ------------------------------------------------------------------------------------------ persistent variant
 // Full-resolution layers (16->16, 32->16, 16->32: 60 % of all conv FLOPs and most of the bytes).  Same math and tile
