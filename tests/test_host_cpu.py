@@ -197,3 +197,25 @@ def test_preprocess_and_infer_symbols_are_bound():
         P.preprocess_ct(torch.zeros(4, 4, 4))
     with pytest.raises(_lib.Mi3dError, match="no CPU fallback"):
         P.remap_labels(torch.zeros(4, 4, 4, dtype=torch.long), "amos_ct")
+
+
+def test_kernel_roofline_tool_assigns_every_launch_of_the_committed_timeline(tmp_path):
+    """tools/kernel_roofline.py walks the committed step timeline by kernel name; a renamed or new kernel family that it does not
+    know would silently shift every later launch to the wrong layer (it happened once in round 3).  The committed round-3 timeline
+    must come out with no unassigned launch and a positive algorithmic model for every conv launch."""
+    import csv
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tl, pmc = os.path.join(root, "profiles", "r03_step_timeline.txt"), os.path.join(root, "profiles", "r03_pmc_step_traffic.json")
+    out = tmp_path / "roofline.csv"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_roofline.py"), tl, pmc, "--out", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert " 0 unassigned" in r.stdout, r.stdout.splitlines()[0]
+    rows = list(csv.DictReader(open(out)))
+    assert len(rows) >= 130
+    for row in rows:
+        if row["kernel"].startswith(("conv3_", "upconv_", "head_loss")):
+            assert float(row["algo_MB"]) > 0 and row["layer"], row
