@@ -227,7 +227,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.0, help="run_training.sh:31 ships --dropout_rate 0.0")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--two-stream", action="store_true", help="weight gradients on a second stream beside the data-gradient chain")
+    ap.add_argument("--no-aux-wgrad", action="store_true",
+                    help="keep every weight gradient on the data-gradient chain (default: the decoder / deep-level ones run on a second stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sclk", action="store_true",
@@ -292,7 +293,7 @@ def main():
             torch.manual_seed(1)
             teacher = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).eval()
         ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt, kd_teacher=teacher,
-                       use_graph=use_graph, two_stream=a.two_stream, overlap_teacher=not a.serial_forwards)
+                       use_graph=use_graph, aux_wgrad=not a.no_aux_wgrad, overlap_teacher=not a.serial_forwards)
         ts.load_batch(x.to(dev), y.to(dev))
     if a.workload == "eval":
         xd, yd = x.to(dev), y.to(dev)

@@ -98,12 +98,27 @@ int mi3d_unet_num_segments(const mi3d_unet_desc* d);
 int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                        const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale,
                        int accumulate, int seg_begin, int seg_end, void* workspace, size_t workspace_bytes,
-                       void* stream, void* aux_stream, void* const* events);
-/* aux_stream/events (both NULL = single stream): a second hipStream_t and 4 hipEvent_t handles (mi3d_event_create);
- * weight-gradient kernels then run on aux_stream beside the data-gradient chain (they only share the dy tensor),
- * forked/joined with the events so the call stays stream-ordered for the caller and hipGraph-capturable. */
+                       void* stream, void* aux_stream, void* const* events, int aux_join);
+/* aux_stream/events (both NULL = single stream): a second hipStream_t and 4 hipEvent_t handles (mi3d_event_create).
+ * The backward's critical path is then the input-gradient chain alone (train_unet.py:225 fixes no order between the two
+ * gradients of a layer): the dy of every decoder conv at the full-resolution levels and of every conv at the deep levels is
+ * kept in its own buffer, and those weight gradients run on aux_stream -- the decoder's under the latency-bound deep-level
+ * chain, the deep levels' under the bandwidth-bound encoder backward -- behind at most three forks (events[0..2], recorded
+ * on `stream`) per call.  events[3] is recorded on aux_stream when it has finished the call's work; aux_join != 0 makes
+ * `stream` wait for it before the call returns (the call is then stream-ordered for the caller), aux_join == 0 leaves that
+ * to the caller: whatever consumes the gradients (optimizer, gradient exchange) and the end of a hipGraph capture must wait
+ * for events[3] / aux_stream.  Results are bit-identical to the single-stream route. */
 int mi3d_event_create(void** event_out);
 int mi3d_event_destroy(void* event);
+/* Route switches: every kernel-selection switch of the library ("no_persist", "no_fused_bwd", "ks_target", ... -- the table
+ * in INTEGRATION.md) is read from the environment (MI3D_<NAME>=<int>) ONCE, when the library is first used; afterwards only
+ * these calls change one.  Debug / test interface: do not call it concurrently with launches; a captured hipGraph keeps the
+ * routes it was captured with.  Unknown names fail. */
+int mi3d_debug_set_route(const char* name, int value);
+int mi3d_debug_get_route(const char* name, int* value_out);
+int mi3d_debug_route_count(void);
+int mi3d_debug_experiments(void);      /* 1: built with make EXPERIMENTS=1 (default-off experiment kernels compiled in) */
+const char* mi3d_debug_route_name(int index);
 /* Measurement hooks (bench.py `roofline`: HIP events around ONE kernel on the stream it is launched on).
  * mi3d_time_next_conv3_bwd_kernel: the (skip+1)-th full-resolution fused conv backward launch from now (mi3d_conv3_backward /
  * mi3d_unet_backward on the calling thread; in the backward of a UNet3D step launch 0 is decoder.L-1.conv1, launch 1
@@ -183,7 +198,8 @@ int mi3d_unet_head_loss_forward(const mi3d_unet_desc* d, const void* const* para
 int mi3d_unet_backward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                             const float* drop_scales, const int64_t* labels, const float* teacher_logits, const mi3d_loss_cfg* cfg,
                             const float* coef, const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin,
-                            int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events);
+                            int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events,
+                            int aux_join);
 size_t mi3d_seg_metrics_workspace_bytes(int C);
 /* out: device float[3] = {iou, dice, accuracy}; D = first spatial dim (reference loop bound, metrics.py:74,101) */
 int mi3d_seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D, int64_t V, float* out,

@@ -2,6 +2,7 @@
 
 The product path has NO fallback: if the HIP library is missing or a tensor is not on the GPU the call raises.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -53,9 +54,14 @@ _SIGS = {
     "mi3d_unet_forward": (i32, [_DP, vp, vp, vp, vp, i32, vp, vp, vp, sz, vp]),
     "mi3d_unet_infer": (i32, [_DP, vp, vp, vp, vp, vp, vp, sz, vp]),
     "mi3d_unet_bn_apply_deferred": (i32, [_DP, vp, vp, vp]),
-    "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp]),
+    "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp, i32]),
     "mi3d_event_create": (i32, [C.POINTER(vp)]),
     "mi3d_event_destroy": (i32, [vp]),
+    "mi3d_debug_set_route": (i32, [C.c_char_p, i32]),
+    "mi3d_debug_get_route": (i32, [C.c_char_p, C.POINTER(C.c_int)]),
+    "mi3d_debug_route_count": (i32, []),
+    "mi3d_debug_experiments": (i32, []),
+    "mi3d_debug_route_name": (C.c_char_p, [i32]),
     "mi3d_debug_occupy_cus": (i32, [i32, i32, vp, i64, vp]),
     "mi3d_set_cu_budget": (i32, [i32]),
     "mi3d_timing_event_create": (i32, [C.POINTER(vp)]),
@@ -71,7 +77,7 @@ _SIGS = {
     "mi3d_head_loss_backward": (i32, [vp, i32, i32, vp, vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mi3d_unet_forward_loss": (i32, [_DP, vp, vp, vp, vp, i32, vp, vp, _LP, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "mi3d_unet_head_loss_forward": (i32, [_DP, vp, vp, vp, _LP, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
-    "mi3d_unet_backward_loss": (i32, [_DP, vp, vp, vp, vp, vp, vp, _LP, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp]),
+    "mi3d_unet_backward_loss": (i32, [_DP, vp, vp, vp, vp, vp, vp, _LP, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp, i32]),
     "mi3d_seg_metrics_workspace_bytes": (sz, [i32]),
     "mi3d_seg_metrics": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp]),
     "mi3d_seg_class_counts": (i32, [vp, vp, i32, i32, i64, vp, vp, vp]),
@@ -151,6 +157,36 @@ def call(name, *args):
     global launches
     launches += 1
     check(getattr(lib(), name)(*args), name)
+
+
+def get_route(name):
+    """Current value of a kernel-selection switch (include/mi3d.h mi3d_debug_get_route; the table is in INTEGRATION.md)."""
+    v = C.c_int()
+    check(lib().mi3d_debug_get_route(name.encode(), C.byref(v)), "mi3d_debug_get_route")
+    return v.value
+
+
+def set_route(name, value):
+    check(lib().mi3d_debug_set_route(name.encode(), int(value)), "mi3d_debug_set_route")
+
+
+def route_names():
+    l = lib()
+    return [l.mi3d_debug_route_name(i).decode() for i in range(l.mi3d_debug_route_count())]
+
+
+@contextlib.contextmanager
+def routes(**kw):
+    """Temporarily change route switches: `with _lib.routes(no_fused_bwd=1): ...` (tests / tools; the library reads the
+    environment only once, at first use).  A hipGraph captured inside keeps the routes it was captured with."""
+    old = {k: get_route(k) for k in kw}
+    try:
+        for k, v in kw.items():
+            set_route(k, v)
+        yield
+    finally:
+        for k, v in old.items():
+            set_route(k, v)
 
 
 def ptr(t):

@@ -2,10 +2,42 @@
 // optimizer and hipGraph helpers.  The whole-network entry points live in plan.hip.
 #include "../../include/mi3d.h"
 #include <stdlib.h>
+#include <string.h>
 
 #include "ops.h"
 
 static_assert(MI3D_LOSS_COEF_FLOATS >= 2 * MI3D_MAX_CLASSES + 4, "coef buffer too small");
+
+// ---- route switches (common.h): one struct, filled from the environment once, changed only through the ABI
+namespace {
+struct RouteEntry { const char* name; int Mi3dRoutes::*field; };
+const RouteEntry ROUTE_TABLE[] = {
+#define MI3D_ROUTE_ENTRY(name, dflt) {#name, &Mi3dRoutes::name},
+    MI3D_ROUTE_LIST(MI3D_ROUTE_ENTRY)
+#undef MI3D_ROUTE_ENTRY
+};
+constexpr int N_ROUTES = sizeof(ROUTE_TABLE) / sizeof(ROUTE_TABLE[0]);
+Mi3dRoutes load_routes() {
+    Mi3dRoutes r;
+    for (int i = 0; i < N_ROUTES; i++) {
+        char env[64] = "MI3D_";
+        size_t n = 5;
+        for (const char* c = ROUTE_TABLE[i].name; *c && n + 1 < sizeof(env); c++) env[n++] = (*c >= 'a' && *c <= 'z') ? *c - 32 : *c;
+        env[n] = 0;
+        const char* v = getenv(env);
+        if (!v) continue;
+        char* end = nullptr;
+        long k = strtol(v, &end, 10);
+        r.*(ROUTE_TABLE[i].field) = (end != v) ? (int)k : 1;
+    }
+    return r;
+}
+Mi3dRoutes& routes_mut() {
+    static Mi3dRoutes r = load_routes();      // thread-safe one-time initialisation
+    return r;
+}
+}  // namespace
+const Mi3dRoutes& mi3d_routes() { return routes_mut(); }
 
 static inline LossCfg to_cfg(const mi3d_loss_cfg* c) {
     LossCfg k;
@@ -16,7 +48,7 @@ static inline LossCfg to_cfg(const mi3d_loss_cfg* c) {
 
 static inline bool use_mfma(int in_dtype, int out_dtype, int Cin, int Cout, int xcs, int ycs) {
     return in_dtype == MI3D_BF16 && out_dtype == MI3D_BF16 && conv3_mfma_supported(Cin, Cout, xcs, ycs) &&
-           !getenv("MI3D_FORCE_DIRECT");
+           !mi3d_routes().force_direct;
 }
 
 extern "C" {
@@ -131,7 +163,7 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
     // the same kernel choice as the whole-network plan (plan.hip block_backward), so the per-operator parity tests pin
     // the kernels the training step runs: both products of a layer in ONE fused launch where that exists
     if (dx && (dW || db) && x_dtype == MI3D_BF16 && use_mfma(dy_dtype, dy_dtype, Cout, Cin, dycs, dxcs) &&
-        use_mfma(x_dtype, dy_dtype, Cin, Cout, xcs, dycs) && !getenv("MI3D_API_UNFUSED")) {
+        use_mfma(x_dtype, dy_dtype, Cin, Cout, xcs, dycs) && !mi3d_routes().api_unfused) {
         size_t wgf = conv3_mfma_wgrad_ws_floats(Cin, Cout, g);
         if (conv3_direct_wgrad_ws_floats(Cin, Cout, g) > wgf) wgf = conv3_direct_wgrad_ws_floats(Cin, Cout, g);
         float* skws = slabs + ((wgf + 63) & ~(size_t)63);
@@ -153,7 +185,7 @@ int mi3d_conv3_backward(int x_dtype, int dy_dtype, const void* x, int xcs, int C
     }
     if (dW || db) {
         if (x_dtype == MI3D_F32 && dy_dtype == MI3D_BF16 && Cin == 1 && xcs == 1 && Cout % 16 == 0 && dycs % 8 == 0 &&
-            !getenv("MI3D_FORCE_DIRECT"))
+            !mi3d_routes().force_direct)
             MI3D_TRY(conv3_mfma_wgrad_c1((const float*)x, dy, dycs, Cout, g, dW, db, accumulate, slabs,
                                          conv3_mfma_wgrad_ws_floats(Cin, Cout, g), s));
         else if (use_mfma(x_dtype, dy_dtype, Cin, Cout, xcs, dycs) && dycs % 8 == 0)
@@ -261,7 +293,7 @@ int mi3d_upconv2_forward(int dtype, const void* x, int xcs, int Cin, const float
     MI3D_CHECK_ARG(workspace_bytes >= mi3d_upconv2_workspace_bytes(Cin, Cout, N, D, H, W), "mi3d_upconv2_forward: workspace too small");
     float* wf = (float*)workspace;
     float* wb = wf + (size_t)cdiv(Cout, 8) * Cin * 64;
-    if (dtype == MI3D_BF16 && upconv2_mfma_supported(Cin, Cout, xcs, ycs) && !getenv("MI3D_FORCE_DIRECT")) {
+    if (dtype == MI3D_BF16 && upconv2_mfma_supported(Cin, Cout, xcs, ycs) && !mi3d_routes().force_direct) {
         MI3D_TRY(upconv2_mfma_pack(w, Cin, Cout, workspace, (hipStream_t)stream));
         return upconv2_mfma_fwd(x, xcs, Cin, workspace, bias, y, ycs, Cout, Geo{N, D, H, W}, (hipStream_t)stream);
     }
@@ -277,7 +309,7 @@ int mi3d_upconv2_backward(int dtype, const void* x, int xcs, int Cin, const floa
     float* wf = (float*)workspace;
     float* wb = wf + (size_t)cdiv(Cout, 8) * Cin * 64;
     float* slabs = (float*)workspace + upconv2_pack_floats(Cin, Cout);
-    if (dtype == MI3D_BF16 && upconv2_mfma_supported(Cin, Cout, xcs, gycs) && (!dx || dxcs % 4 == 0) && !getenv("MI3D_FORCE_DIRECT")) {
+    if (dtype == MI3D_BF16 && upconv2_mfma_supported(Cin, Cout, xcs, gycs) && (!dx || dxcs % 4 == 0) && !mi3d_routes().force_direct) {
         MI3D_TRY(upconv2_mfma_pack(w, Cin, Cout, workspace, (hipStream_t)stream));
         return upconv2_mfma_bwd(x, xcs, Cin, gy, gycs, Cout, workspace, dx, dxcs, dW, db, accumulate, slabs,
                                 upconv2_mfma_bwd_ws_floats(Cin, Cout, g), g, (hipStream_t)stream);
@@ -294,6 +326,28 @@ int mi3d_ndhwc_to_ncdhw(int dtype, const void* src, int scs, float* dst, int C, 
     MI3D_CHECK_ARG(src && dst, "mi3d_ndhwc_to_ncdhw: null pointer");
     return ndhwc_to_ncdhw(dtype, src, scs, dst, C, N, V, (hipStream_t)stream);
 }
+
+int mi3d_debug_set_route(const char* name, int value) {
+    MI3D_CHECK_ARG(name, "mi3d_debug_set_route: null name");
+    for (int i = 0; i < N_ROUTES; i++)
+        if (!strcmp(name, ROUTE_TABLE[i].name)) { routes_mut().*(ROUTE_TABLE[i].field) = value; return 0; }
+    MI3D_CHECK_ARG(false, "mi3d_debug_set_route: unknown route '%s'", name);
+}
+int mi3d_debug_get_route(const char* name, int* value_out) {
+    MI3D_CHECK_ARG(name && value_out, "mi3d_debug_get_route: null argument");
+    for (int i = 0; i < N_ROUTES; i++)
+        if (!strcmp(name, ROUTE_TABLE[i].name)) { *value_out = routes_mut().*(ROUTE_TABLE[i].field); return 0; }
+    MI3D_CHECK_ARG(false, "mi3d_debug_get_route: unknown route '%s'", name);
+}
+int mi3d_debug_experiments(void) {
+#ifdef MI3D_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+int mi3d_debug_route_count(void) { return N_ROUTES; }
+const char* mi3d_debug_route_name(int i) { return (i >= 0 && i < N_ROUTES) ? ROUTE_TABLE[i].name : nullptr; }
 
 int mi3d_event_create(void** event_out) {
     MI3D_CHECK_ARG(event_out, "mi3d_event_create: null output");

@@ -580,7 +580,7 @@ size_t bn_ws_floats(int C) { return (size_t)MAXBLK * 2 * C + 3 * (size_t)C; }
 // "small" = a deep-level tensor whose reduction fits a few workgroups: <= SMALL_ROWS partial rows, finished by the consumer
 constexpr int64_t SMALL_ELEMS = 2 << 20;
 inline bool bn_small(int C, int64_t M) {
-    return C >= 4 && C <= MAXC_BN && (C & (C - 1)) == 0 && M * C <= SMALL_ELEMS && !getenv("MI3D_NO_SMALL_BN");
+    return C >= 4 && C <= MAXC_BN && (C & (C - 1)) == 0 && M * C <= SMALL_ELEMS && !mi3d_routes().no_small_bn;
 }
 // number of partial rows for a small tensor
 inline int bn_small_rows(int nblk, int C) { return nblk > SMALL_ROWS ? SMALL_ROWS : nblk; }

@@ -40,6 +40,42 @@ void mi3d_set_error(const char* fmt, ...);
         if (rc_ != 0) return rc_; \
     } while (0)
 
+// ---- route switches ------------------------------------------------------------------------------
+// Every kernel-selection switch of the library lives in ONE struct.  It is filled from the environment exactly once, at
+// the first use in the process (MI3D_<NAME>=<integer>; a variable that is set to something non-numeric counts as 1), so a
+// captured hipGraph and later eager launches cannot disagree and no launch path calls getenv().  Tests and tools change a
+// route through the ABI (mi3d_debug_set_route), not through setenv.  X(name, default)
+#define MI3D_ROUTE_LIST(X)                                                                                          \
+    X(force_direct, 0)      /* fp32-FMA kernels everywhere (no MFMA path) */                                        \
+    X(no_planar, 0)         /* interleaved instead of planar skip/up halves at C = 16 */                            \
+    X(no_persist, 0)        /* generic instead of persistent full-resolution conv kernels */                        \
+    X(no_c1_mfma, 0)        /* first layer (Cin = 1) forward on the fp32 kernel */                                  \
+    X(no_conv1_mfma, 0)     /* 1x1x1 head backward without the matrix cores */                                      \
+    X(no_head_loss, 0)      /* head and loss as separate passes (logits / dlogits through memory) */                \
+    X(no_pool_fuse, 0)      /* BatchNorm apply and MaxPool3d as two launches */                                     \
+    X(no_small_bn, 0)       /* deep levels: statistics finished by a finalize launch, not the consumer's prologue */\
+    X(no_defer_tail, 0)     /* split-K input gradients finished by their own pass */                                \
+    X(no_pend_slabs, 0)     /* weight-gradient slab sums launched on their own */                                   \
+    X(no_upbwd_carry, 0)    /* the decoder conv's slab sum is not carried across the transposed conv's backward */  \
+    X(no_bwd_tail, 0)       /* split-K finish and slab sum of a fused backward as two launches */                   \
+    X(no_fused_bwd, 0)      /* weight gradient and input gradient of a conv layer in two launches, every level */   \
+    X(no_fused_bwd_p, 0)    /* ... full-resolution (persistent) layers only */                                      \
+    X(no_fused_bwd_big, 0)  /* ... level-1 (16-wide tile) layers only */                                            \
+    X(no_fused_upbwd, 0)    /* transposed conv: weight gradient and input gradient in two launches */               \
+    X(api_unfused, 0)       /* mi3d_conv3_backward: stand-alone kernels instead of the step's fused launches */     \
+    X(conv8, 1)             /* eight-wave forward conv for levels 1-4 (0: four-wave kernels) */                     \
+    X(ks_target, 128)       /* split-K workgroup target, forward */                                                 \
+    X(ks_target_bwd, 128)   /* split-K workgroup target, input gradient */                                          \
+    X(fused_wg_target, 288) /* weight-gradient workgroups of a fused deep-level backward launch */                  \
+    X(no_defer_wgrad, 0)    /* round 4: weight gradients stay on the data-gradient chain even with an aux stream */ \
+    X(conv_dma, 0)          /* MI3D_EXPERIMENTS builds only: LDS-DMA staging in the Cout = 16 persistent forward conv */
+struct Mi3dRoutes {
+#define MI3D_ROUTE_FIELD(name, dflt) int name = dflt;
+    MI3D_ROUTE_LIST(MI3D_ROUTE_FIELD)
+#undef MI3D_ROUTE_FIELD
+};
+const Mi3dRoutes& mi3d_routes();      // api.hip
+
 #ifdef __HIPCC__
 #define MI3D_HD __host__ __device__
 #else

@@ -837,6 +837,7 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_kernel(const bf16* 
                                              nullptr, relu);
 }
 
+#ifdef MI3D_EXPERIMENTS      // default-off experiment routes are compiled only into experiment builds (make EXPERIMENTS=1)
 // ------------------------------------------------------------------------ persistent variant with asynchronous staging
 // Cout = 16 forward layers at full resolution (16 -> 16, 32 -> 16).  Same tile, K-step order and epilogue as the kernel
 // above; what changes is how a workgroup's phases relate.  There, a chunk is  barrier | LDS writes | barrier | issue the next
@@ -1061,21 +1062,34 @@ __global__ __launch_bounds__(BLK, 2) void conv3_mfma_persist_dma_kernel(const bf
     }
 }
 
-constexpr bool CONV8_DEFAULT = true;        // round 3 A/B: level-1 forward convs 112 -> 103 us, deep 153 -> 143 us per step
-constexpr int PERSIST_WGS = 512;
+#endif  // MI3D_EXPERIMENTS
+
+// eight-wave kernels (route conv8, default on): round 3 A/B level-1 forward convs 112 -> 103 us, deep 153 -> 143 us per step
 // CU budget (mi3d_set_cu_budget): CUs the caller wants left free of persistent workgroups because a collective kernel is
 // resident on them (data-parallel step: the gradient all-reduce runs beside the encoder backward).  A persistent grid sized
 // for all 256 CUs would otherwise run a second, partial round on the CUs it has to share.
 static thread_local int g_cu_budget = 0;
 extern "C" int mi3d_set_cu_budget(int cus) { g_cu_budget = cus < 0 ? 0 : (cus > 128 ? 128 : cus); return 0; }
-inline int persist_cus() { return 256 - g_cu_budget; }
+// compute units of the device (256 on MI355X), queried once per process; the plan sizes its partial-row buffers with the
+// same number, so it must not change between mi3d_unet_workspace_bytes and the launches
+inline int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8)
+            v = 256;
+        (void)hipGetLastError();
+        return v;
+    }();
+    return n;
+}
+inline int persist_cus() { return device_cus() - g_cu_budget; }
 inline bool persist_ok(int Cin, int Cout, Geo g) {
     // 16 -> 32 (two co blocks, 256 VGPRs): only worth it with >= 2 tiles per workgroup; the one-tile-per-workgroup
     // generic kernel is faster below that (level 1 of the 96^3 net)
     int64_t nt = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
     if (Cin == 16 && Cout == 32 && nt < 1024) return false;
     return g.W >= 32 && g.H >= 16 && ((Cin == 16 && Cout == 16) || (Cin == 32 && Cout == 16) || (Cin == 16 && Cout == 32)) &&
-           !getenv("MI3D_NO_PERSIST");
+           !mi3d_routes().no_persist;
 }
 inline int persist_grid(int Cin, int Cout, Geo g) {
     int64_t nt = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 16);
@@ -1120,8 +1134,7 @@ int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bia
     dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)), (unsigned)ksplit);
     // eight-wave variant (see conv3_mfma8_kernel); MI3D_CONV8=0 selects the four-wave kernels
     static_assert((TYB * TXB) % 2 == 0, "tile shapes used here have an even number of M-blocks per slice");
-    const char* e8 = getenv("MI3D_CONV8");
-    const bool w8 = e8 ? atoi(e8) != 0 : CONV8_DEFAULT;
+    const bool w8 = mi3d_routes().conv8 != 0;
     constexpr size_t lds8 = conv8_lds(TY, TX, COB);
 #define LC8(ST_, SK_, PART_, BIAS_, RELU_)                                                                                     \
     do {                                                                                                                       \
@@ -1158,7 +1171,7 @@ inline int pick_ksplit(int Cin, int Cout, Geo g, int target_override = 0) {
     // split-K workgroup target.  Round 2 (four-wave kernels): 128 / 256 / 512 / 1024 -> 2.375 / 2.350 / 2.395 / 2.421 ms.  Round 3
     // (eight-wave kernels: a workgroup's chain is half as long, fewer and fatter workgroups win; more layers keep their BatchNorm
     // partial sums in the conv epilogue): 64 / 96 / 128 / 192 / 256 / 384 / 512 -> 2.252 / 2.229 / 2.219 / 2.221 / 2.263 / 2.265 / 2.286 ms
-    static const int target = getenv("MI3D_KS_TARGET") ? atoi(getenv("MI3D_KS_TARGET")) : 128;
+    const int target = mi3d_routes().ks_target;
     const int tgt = target_override > 0 ? (target_override < target ? target_override : target) : target;
     while (wgs * k < tgt && k * 2 <= nchunk && nchunk % (k * 2) == 0 && k < 16) k *= 2;
     return k;
@@ -1226,8 +1239,7 @@ bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g) { return pick_ksplit(Cin, 
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g) { return persist_ok(Cin, Cout, g); }
 
 int conv3_bwd_ks_target() {
-    const char* e_k = getenv("MI3D_KS_TARGET_BWD");
-    int kst = e_k ? atoi(e_k) : 128;          // pick_ksplit clamps it to the forward target (the planned split-K scratch)
+    int kst = mi3d_routes().ks_target_bwd;    // pick_ksplit clamps it to the forward target (the planned split-K scratch)
     return kst < 1 ? 1 : kst;
 }
 
@@ -1249,7 +1261,8 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         // Cout = 16: asynchronous-staging variant (the tensor must be addressable with 32-bit byte offsets)
         // OFF by default: the kernels are 6-9 % faster, but with them in the step the part runs at 2350 instead of
         // 2392 MHz (rocm-smi during bench.py, at LOWER package power) and the step gets 15-40 us slower
-        const bool dma = Cout == 16 && (Cin == 16 || Cin == 32) && getenv("MI3D_CONV_DMA") &&
+#ifdef MI3D_EXPERIMENTS
+        const bool dma = Cout == 16 && (Cin == 16 || Cin == 32) && mi3d_routes().conv_dma &&
                          (size_t)g.M() * (size_t)(xh.on() ? 2 * xcs : xcs) * 2 < (size_t)DMA_OOB;
         if (dma) {
             size_t lds = 2 * (size_t)DMA_TILE_BYTES + 4 * 16 * 2 * sizeof(float);
@@ -1265,6 +1278,7 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
             MI3D_LAUNCH_CHECK();
             return 0;
         }
+#endif  // MI3D_EXPERIMENTS
         if (Cin == 16 && Cout == 16) PK(1, 1);
         else if (Cin == 32) PK(1, 2);
         else PK(2, 1);
@@ -1956,10 +1970,12 @@ size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g) {
     return (size_t)wgrad_cfg(Cin, Cout, g).nsb * ((size_t)Cout * Cin * 27 + Cout);
 }
 
+bool conv3_mfma_big_geo(Geo g) { return big_geo(g); }
+
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
-                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh, SlabJob* pend) {
+                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh, SlabJob* pend, int wg_target) {
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0, "conv3_mfma_wgrad: unsupported channels");
-    WgCfg c = wgrad_cfg(Cin, Cout, g);
+    WgCfg c = wgrad_cfg(Cin, Cout, g, wg_target);
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
     MI3D_CHECK_ARG(ws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_wgrad: workspace too small");
     const bf16* xp = (const bf16*)x; const bf16* dp = (const bf16*)dy;
@@ -1981,8 +1997,8 @@ extern "C" int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_eve
 
 // full-resolution layers: dgrad on the persistent body (Cout -> Cin must be one of its shapes)
 bool conv3_mfma_bwd_fused_persist_ok(int Cin, int Cout, int xcs, int dycs, Geo g) {
-    return persist_ok(Cout, Cin, g) && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && !getenv("MI3D_NO_FUSED_BWD") &&
-           !getenv("MI3D_NO_FUSED_BWD_P");
+    return persist_ok(Cout, Cin, g) && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && !mi3d_routes().no_fused_bwd &&
+           !mi3d_routes().no_fused_bwd_p;
 }
 int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
                                  int dxcs, Geo g, float* dW, float* db, int accumulate, float* wgws, size_t wgws_floats,
@@ -2033,9 +2049,15 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
 bool conv3_mfma_bwd_fused_ok(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g) {
     // generic dgrad tilings with two output blocks (Cin % 32) -- not the persistent full-resolution kernels; both
     // products on the MFMA path
-    if (big_geo(g) && (persist_ok(Cout, Cin, g) || getenv("MI3D_NO_FUSED_BWD_BIG"))) return false;
+    if (big_geo(g) && (persist_ok(Cout, Cin, g) || mi3d_routes().no_fused_bwd_big)) return false;
     return Cin % 32 == 0 && conv3_mfma_supported(Cin, Cout, xcs, dycs) && dycs % 8 == 0 && dxcs % 8 == 0 &&
-           !getenv("MI3D_NO_FUSED_BWD");
+           !mi3d_routes().no_fused_bwd;
+}
+
+int conv3_mfma_bwd_wg_target(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g) {
+    if (conv3_mfma_bwd_fused_persist_ok(Cin, Cout, xcs, dycs, g)) return persist_cus();
+    if (conv3_mfma_bwd_fused_ok(Cin, Cout, xcs, dycs, dxcs, g)) return mi3d_routes().fused_wg_target;
+    return 0;
 }
 
 int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, const void* wp_dgrad, void* dx,
@@ -2048,8 +2070,7 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     // ~288 workgroups instead of the stand-alone kernel's 512 it leaves fewer, fatter slabs (less slab traffic to sum) and lets
     // the input-gradient workgroups start earlier.  Scan at 96^3 (tools/abenv.py, ms/step): 64: 2.71, 128: 2.42, 192: 2.33,
     // 256: 2.32, 288: 2.286, 320: 2.288, 352: 2.296, 384: 2.303, 448: 2.309, 512: 2.313.  MI3D_FUSED_WG_TARGET overrides
-    const char* e_t = getenv("MI3D_FUSED_WG_TARGET");
-    WgCfg c = wgrad_cfg(Cin, Cout, g, e_t ? atoi(e_t) : 288);
+    WgCfg c = wgrad_cfg(Cin, Cout, g, mi3d_routes().fused_wg_target);
     int64_t nW = (int64_t)Cout * Cin * 27, slab_sz = nW + Cout;
     MI3D_CHECK_ARG(wgws_floats >= (size_t)c.nsb * slab_sz, "conv3_mfma_bwd_fused: workspace too small");
     bool big = big_geo(g);
@@ -2080,7 +2101,7 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
         *ks_deferred = ks;
         return wgrad_slab_sum(wgws, c.nsb, Cin, Cout, dW, db, accumulate, s, pend);
     }
-    if (ks > 1 && !getenv("MI3D_NO_BWD_TAIL")) {
+    if (ks > 1 && !mi3d_routes().no_bwd_tail) {
         int64_t tot = g.M() * (Cin / 8);
         TailArgs t;
         t.part = skws; t.ks = ks; t.M = g.M(); t.C = Cin; t.y = (bf16*)dx; t.ycs = dxcs;

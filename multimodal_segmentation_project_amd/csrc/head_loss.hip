@@ -1076,7 +1076,7 @@ int conv1_bwd(int dtype, const void* z, int zcs, int Cin, const float* w, const 
     int nslab = 0;
     // every slab element is written by exactly one (blockIdx.x, blockIdx.y, blockIdx.z) block
     if (dtype == MI3D_BF16 && Cin % 16 == 0 && zcs % 8 == 0 && al16(z) && (!dz || (dzcs % 4 == 0 && ((uintptr_t)dz % 8) == 0)) &&
-        !getenv("MI3D_NO_CONV1_MFMA")) {
+        !mi3d_routes().no_conv1_mfma) {
         const int capb = 1024;             // 8-wave workgroups, one slab each (conv1_bwd_ws_floats covers 8192)
         int64_t want = (V + C1W * 32 - 1) / (C1W * 32);       // voxels per workgroup iteration
         int bx = capb / N < 1 ? 1 : capb / N;
@@ -1190,11 +1190,11 @@ int seg_metrics(const float* logits, const int64_t* labels, int N, int C, int D,
 
 // ---- head + loss fused (training step)
 bool head_loss_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg) {
-    return dtype == MI3D_BF16 && Cin % CINB == 0 && zcs % 8 == 0 && al16(z) && C >= 1 && C <= 4 && !getenv("MI3D_NO_HEAD_LOSS");
+    return dtype == MI3D_BF16 && Cin % CINB == 0 && zcs % 8 == 0 && al16(z) && C >= 1 && C <= 4 && !mi3d_routes().no_head_loss;
 }
 bool head_loss_bwd_ok(int dtype, const void* z, int zcs, int Cin, int C, LossCfg cfg, const void* dz, int dzcs) {
     return head_loss_ok(dtype, z, zcs, Cin, C, cfg) && Cin == 16 && (!dz || (dzcs % 4 == 0 && ((uintptr_t)dz % 8) == 0)) &&
-           !getenv("MI3D_NO_CONV1_MFMA");
+           !mi3d_routes().no_conv1_mfma;
 }
 
 int head_loss_fwd(const void* z, int zcs, int Cin, const float* w, const float* bias, const int64_t* labels, const float* teacher,

@@ -62,7 +62,13 @@ int conv3_bwd_ks_target();
 
 size_t conv3_mfma_wgrad_ws_floats(int Cin, int Cout, Geo g);
 int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, int Cout, Geo g, float* dW, float* db,
-                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh = Halves(), SlabJob* pend = nullptr);
+                     int accumulate, float* ws, size_t ws_floats, hipStream_t s, Halves xh = Halves(), SlabJob* pend = nullptr,
+                     int wg_target = 0);
+// wg_target > 0: workgroup target of the launch (0 = two per CU).  conv3_mfma_bwd_wg_target = the target the layer's FUSED
+// backward launch uses for its weight-gradient half (0: the layer has no fused launch): a stand-alone weight gradient launched
+// with it cuts the tiles into the same slabs, i.e. sums in the same order and produces the same bits as the fused route
+int conv3_mfma_bwd_wg_target(int Cin, int Cout, int xcs, int dycs, int dxcs, Geo g);
+bool conv3_mfma_big_geo(Geo g);      // 16-wide tiles (levels 0-1 of a 96^3 net) vs the 8-wide deep-level tiling
 // pend != NULL (here and below): the final slab sum is NOT launched; its job is returned for the caller to attach to
 // the next kernel on the chain (bn_bwd) or to run with slab_job_launch
 

@@ -24,6 +24,13 @@ struct HalfP {
     int pidx, bidx;
     int64_t drop_off;
     bool mfma;                    // bf16 implicit-GEMM path (conv3_mfma.hip) vs direct fp32-FMA path
+    // Deferred weight gradient (round 4): with an aux stream the layer's dy gets its OWN buffer (dyk) that stays alive, the
+    // data-gradient chain runs the input-gradient conv alone, and the weight gradient is launched later on the aux stream.
+    //   1 = decoder layer at a 16-wide-tile level (levels 0-1 at 96^3): runs under the latency-bound deep-level chain
+    //   2 = any layer at a deep level (8-wide tiles): runs under the bandwidth-bound encoder backward of levels 1-0
+    //   0 = encoder layers at the 16-wide levels: nothing left to hide under, they keep the fused launch
+    int defer;
+    size_t dyk;
 };
 struct BlockP {
     int level;
@@ -57,7 +64,9 @@ struct Plan {
         return h;
     }
     size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sB2, sC;
-    size_t bnws, wgws, wgws2, statpart, skws;
+    size_t bnws, wgws, wgws2, wgws3, statpart, skws;
+    // (block, half) after whose BatchNorm backward the pending deferred weight gradients of group 1 / 2 go to the aux stream
+    int flush_b[2], flush_h[2];
     size_t wgws_floats;
     size_t total;
     int up_pidx(int i) const { return 8 * (L + 1) + 2 * i; }
@@ -98,7 +107,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
 
     for (int l = 0; l < p.L; l++)
         p.planar[l] = p.dt == MI3D_BF16 && p.C[l] % 16 == 0 && conv3_mfma_halves_ok(2 * p.C[l], p.C[l], p.geo[l]) &&
-                      conv3_mfma_halves_ok(p.C[l], 2 * p.C[l], p.geo[l]) && !getenv("MI3D_FORCE_DIRECT") && !getenv("MI3D_NO_PLANAR");
+                      conv3_mfma_halves_ok(p.C[l], 2 * p.C[l], p.geo[l]) && !mi3d_routes().force_direct && !mi3d_routes().no_planar;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     int64_t drop_off = 0;
@@ -119,7 +128,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
             H.Cout = cout;
             H.y = take((size_t)g.M() * cout * p.esz);
             H.stat = take((size_t)4 * cout * sizeof(float));
-            H.mfma = p.dt == MI3D_BF16 && conv3_mfma_supported(H.Cin, H.Cout, 16, 16) && !getenv("MI3D_FORCE_DIRECT");
+            H.mfma = p.dt == MI3D_BF16 && conv3_mfma_supported(H.Cin, H.Cout, 16, 16) && !mi3d_routes().force_direct;
             if (H.mfma) {
                 H.wpf = take(conv3_mfma_pack_elems(H.Cin, H.Cout) * 2);
                 H.wpd = take(conv3_mfma_pack_elems(H.Cin, H.Cout) * 2);
@@ -136,13 +145,17 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
             H.bidx = 6 * b + 3 * h;
             H.drop_off = drop_off;
             drop_off += (int64_t)d->N * cout;
-            bool c1 = p.dt == MI3D_BF16 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT");
+            bool c1 = p.dt == MI3D_BF16 && H.Cin == 1 && H.Cout % 16 == 0 && !mi3d_routes().force_direct;
             if (c1) {
                 size_t sp = (size_t)conv3_c1_fwd_stat_blocks(g) * 2 * cout;
                 if (sp > statpart_floats) statpart_floats = sp;
             }
             size_t wf = (H.mfma || c1) ? conv3_mfma_wgrad_ws_floats(H.Cin, H.Cout, g) : conv3_direct_wgrad_ws_floats(H.Cin, H.Cout, g);
             if (wf > wg_floats) wg_floats = wf;
+            // the dy buffers are part of the layout whatever the route says (a route changed between the workspace query and a
+            // launch must not move anything)
+            H.defer = !H.mfma ? 0 : !conv3_mfma_big_geo(g) ? 2 : (b > p.L ? 1 : 0);
+            H.dyk = H.defer ? take((size_t)g.M() * cout * p.esz) : 0;
         }
         B.z1 = take((size_t)g.M() * cout * p.esz);
         if ((size_t)g.M() * cout > maxCM) maxCM = (size_t)g.M() * cout;
@@ -161,7 +174,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
         int l = p.L - 1 - i;
         p.zd[i] = take((size_t)p.geo[l].M() * p.C[l] * p.esz);
         p.up_mfma[i] = p.dt == MI3D_BF16 && upconv2_mfma_supported(2 * p.C[l], p.C[l], 2 * p.C[l], 2 * p.C[l]) &&
-                       !getenv("MI3D_FORCE_DIRECT");
+                       !mi3d_routes().force_direct;
         p.upw[i] = take(p.up_mfma[i] ? upconv2_mfma_pack_elems(2 * p.C[l], p.C[l]) * 2
                                      : upconv2_pack_floats(2 * p.C[l], p.C[l]) * sizeof(float));
         size_t wf = p.up_mfma[i] ? upconv2_mfma_bwd_ws_floats(2 * p.C[l], p.C[l], p.geo[l + 1])
@@ -181,6 +194,16 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     p.wgws_floats = wg_floats;
     p.wgws = take(wg_floats * sizeof(float));
     p.wgws2 = take(wg_floats * sizeof(float));
+    p.wgws3 = take(wg_floats * sizeof(float));       // slabs of the weight gradients on the aux stream
+    // backward order of the conv layers: decoder.L-1 .. decoder.0 (level 0 first), bottleneck, encoder.L-1 .. 0; half 1 then 0
+    for (int k = 0; k < 2; k++) p.flush_b[k] = p.flush_h[k] = -1;
+    for (int q = 0; q < p.nblk; q++) {
+        int b = 2 * p.L - q;
+        for (int h = 1; h >= 0; h--) {
+            int dfr = p.blk[b].h[h].defer;
+            if (dfr) { p.flush_b[dfr - 1] = b; p.flush_h[dfr - 1] = h; }
+        }
+    }
     p.total = off;
     return 0;
 }
@@ -190,12 +213,15 @@ struct Ctx {
     char* ws;
     const void* const* params;
     hipStream_t s;
-    // optional second stream: weight gradients run beside the data-gradient chain (fork/join with events; works
-    // eagerly and inside a hipGraph capture).  ev = {fork0, fork1, done0, done1}
+    // optional second stream: the DEFERRED weight gradients (HalfP::defer) run there, off the data-gradient chain, behind
+    // at most three forks per call (events 0..2) and one join (event 3); works eagerly and inside a hipGraph capture
     hipStream_t s2 = nullptr;
     hipEvent_t* ev = nullptr;
     mutable int seq = 0;
-    mutable bool rec[2] = {false, false};       // done-events recorded by this call (aux-stream wgrads in flight)
+    struct DJob { int b, h, wg_target; };
+    mutable DJob dq[4 * MAXL + 2];             // weight gradients whose dy is ready and that have not been launched yet
+    mutable int ndq = 0, nfork = 0;
+    mutable bool aux_used = false;
     mutable bool packed = false;      // weight packs already done by the one-launch pack_all
     // one pending weight-gradient slab sum: it rides in the next BatchNorm-backward reduction launch (or is flushed
     // with its own launch when another one arrives first / at the end of the call)
@@ -277,8 +303,8 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
                                     training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
                                     (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr));
             fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
-        } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT") &&
-                   !getenv("MI3D_NO_C1_MFMA")) {
+        } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !mi3d_routes().force_direct &&
+                   !mi3d_routes().no_c1_mfma) {
             // first layer on the matrix cores (taps are the K dimension), BN partial sums fused like the other convs
             MI3D_TRY(conv3_c1_fwd_mfma((const float*)in, c.P(H.pidx), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
                                        training ? c.at<float>(p.statpart) : nullptr, c.s));
@@ -315,6 +341,34 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
     return 0;
 }
 
+// Launch the queued weight gradients on the aux stream, ordered after everything the compute stream has enqueued so far
+// (their dy buffers are complete).  They run one after the other there, each followed by its slab sum, sharing the third
+// slab workspace; nothing on the compute stream waits for them before the end of the step (unet_backward_impl joins).
+int flush_deferred(const Ctx& c, const float* x, void* const* grads, int accumulate) {
+    if (c.ndq == 0) return 0;
+    const Plan& p = c.p;
+    MI3D_CHECK_ARG(c.nfork < 3, "flush_deferred: more than three forks in one call");
+    hipEvent_t fe = c.ev[c.nfork++];
+    MI3D_HIP(hipEventRecord(fe, c.s));
+    MI3D_HIP(hipStreamWaitEvent(c.s2, fe, 0));
+    for (int q = 0; q < c.ndq; q++) {
+        int b = c.dq[q].b, h = c.dq[q].h;
+        const BlockP& B = p.blk[b];
+        const HalfP& H = B.h[h];
+        Geo g = p.geo[B.level];
+        const void* xin; int xcs, xdt;
+        block_input(c, b, x, xin, xcs, xdt);
+        const void* in = h == 0 ? xin : c.at(B.z1);
+        int ics = h == 0 ? xcs : H.Cout;
+        MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, c.at(H.dyk), H.Cout, H.Cout, g, (float*)grads[H.pidx], (float*)grads[H.pidx + 1], accumulate,
+                                  c.at<float>(p.wgws3), p.wgws_floats, c.s2, (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), nullptr,
+                                  c.dq[q].wg_target));
+    }
+    c.ndq = 0;
+    c.aux_used = true;
+    return 0;
+}
+
 // backward of block b given dz2 (dtype T, stride dzcs); writes dxin (may be NULL) with stride dxcs
 int block_backward(const Ctx& c, int b, const float* x, void* const* grads, const float* drop, const void* dz2,
                    int dzcs, void* dxin, int dxcs, int accumulate) {
@@ -324,15 +378,15 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
     const void* xin; int xcs, xdt;
     block_input(c, b, x, xin, xcs, xdt);
     auto G = [&](int i) { return grads ? (float*)grads[i] : nullptr; };
-    // measured (96^3, hipGraph): any second stream in the captured graph costs ~130 us/step more than it hides -> off by default
-    bool two = c.s2 != nullptr && c.ev != nullptr;
+    const bool aux = c.s2 != nullptr && c.ev != nullptr && !mi3d_routes().no_defer_wgrad;
     const float* dz_skp = nullptr;      // dz of half 0 left as split-K partials by half 1's fused backward launch
     int dz_ks = 0;
     for (int h = 1; h >= 0; h--) {
         const HalfP& H = B.h[h];
         int k = c.seq++;
-        void* dyb = c.at((k & 1) ? p.sB2 : p.sB);            // dy ping-pong: the aux-stream wgrad may still read the other one
-        if (c.rec[k & 1]) { MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + (k & 1)], 0)); c.rec[k & 1] = false; }
+        // deferred weight gradient: dy goes to the layer's own buffer, which nobody overwrites before the aux stream has read it
+        const bool dfr = aux && H.defer && (G(H.pidx) || G(H.pidx + 1));
+        void* dyb = dfr ? c.at(H.dyk) : c.at((k & 1) ? p.sB2 : p.sB);
         const void* dz = h == 1 ? dz2 : c.at(p.sC);
         int dcs = h == 1 ? dzcs : H.Cout;
         MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
@@ -345,7 +399,24 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
         void* dx_f = h == 1 ? c.at(p.sC) : dxin;
         int dxs_f = h == 1 ? H.Cin : dxcs;
-        if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && conv3_mfma_bwd_fused_persist_ok(H.Cin, H.Cout, ics, H.Cout, g)) {
+        if (dfr) {
+            // the chain runs the input-gradient conv alone; the weight gradient is queued for the aux stream.  Its slab partition
+            // is the fused launch's (conv3_mfma_bwd_wg_target), the input gradient uses the fused launch's split-K factor and the
+            // same K order: both routes produce the same bits
+            c.dq[c.ndq++] = Ctx::DJob{b, h, conv3_mfma_bwd_wg_target(H.Cin, H.Cout, ics, H.Cout, dx_f ? dxs_f : 8, g)};
+            for (int q = 0; q < 2; q++)
+                if (b == p.flush_b[q] && h == p.flush_h[q]) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+            if (dx_f) {
+                const bool defer = h == 1 && c.defer_slabs && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
+                int ksd = 0;
+                MI3D_TRY(conv3_mfma_fwd(dyb, H.Cout, H.Cout, c.at(H.wpd), nullptr, dx_f, dxs_f, H.Cin, g, nullptr,
+                                        (dxs_f % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s, Halves(),
+                                        (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), defer ? &ksd : nullptr, 0, conv3_bwd_ks_target()));
+                if (ksd > 0) { dz_skp = c.at<float>(p.skws); dz_ks = ksd; }
+            }
+            continue;
+        }
+        if (H.mfma && dx_f && (G(H.pidx) || G(H.pidx + 1)) && conv3_mfma_bwd_fused_persist_ok(H.Cin, H.Cout, ics, H.Cout, g)) {
             Halves hv = (h == 0 && b > p.L) ? p.halves(B.level) : Halves();
             SlabJob* ps = c.pend_slot();
             MI3D_TRY(conv3_mfma_bwd_fused_persist(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx),
@@ -353,12 +424,12 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             c.pend_filled();
             continue;
         }
-        if (H.mfma && !two && dx_f && (G(H.pidx) || G(H.pidx + 1)) && !(h == 0 && b > p.L && p.planar[B.level]) &&
+        if (H.mfma && dx_f && (G(H.pidx) || G(H.pidx + 1)) && !(h == 0 && b > p.L && p.planar[B.level]) &&
             conv3_mfma_bwd_fused_ok(H.Cin, H.Cout, ics, H.Cout, dxs_f, g)) {
             SlabJob* ps = c.pend_slot();
             // half 1's input gradient feeds straight into half 0's BatchNorm-backward reduction: leave a split-K result as
             // partials and let that reduction finish it (one launch less on the chain)
-            bool defer = h == 1 && ps && dxs_f % 8 == 0 && !getenv("MI3D_NO_DEFER_TAIL");
+            bool defer = h == 1 && ps && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
             int ksd = 0;
             MI3D_TRY(conv3_mfma_bwd_fused(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx), G(H.pidx + 1),
                                           accumulate, c.at<float>(p.wgws), p.wgws_floats, c.at<float>(p.skws), c.s, ps,
@@ -370,24 +441,17 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         if (G(H.pidx) || G(H.pidx + 1)) {
             hipStream_t ws_ = c.s;
             float* wgws = c.at<float>(p.wgws);
-            SlabJob* ps = two ? nullptr : c.pend_slot();
-            if (two) {
-                MI3D_HIP(hipEventRecord(c.ev[k & 1], c.s));
-                MI3D_HIP(hipStreamWaitEvent(c.s2, c.ev[k & 1], 0));
-                ws_ = c.s2;
-                wgws = c.at<float>(p.wgws2);
-            }
+            SlabJob* ps = c.pend_slot();
             if (H.mfma)
                 MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
                                           wgws, p.wgws_floats, ws_, (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), ps));
-            else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT"))
+            else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !mi3d_routes().force_direct)
                 MI3D_TRY(conv3_mfma_wgrad_c1((const float*)in, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1), accumulate,
                                              wgws, p.wgws_floats, ws_, ps));
             else
                 MI3D_TRY(conv3_direct_wgrad(idt, p.dt, in, ics, H.Cin, dyb, H.Cout, H.Cout, g, G(H.pidx), G(H.pidx + 1),
                                             accumulate, wgws, p.wgws_floats, ws_));
-            if (!two) c.pend_filled();
-            if (two) { MI3D_HIP(hipEventRecord(c.ev[2 + (k & 1)], c.s2)); c.rec[k & 1] = true; }
+            c.pend_filled();
         }
         void* dx = h == 1 ? c.at(p.sC) : dxin;
         int dxs = h == 1 ? H.Cin : dxcs;
@@ -426,8 +490,8 @@ int block_infer(const Ctx& c, int b, const float* x) {
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), fbias, zo, zocs, H.Cout, g, nullptr,
                                     (zocs % 8 == 0 && ((uintptr_t)zo % 16) == 0) ? c.at<float>(p.skws) : nullptr, c.s,
                                     (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), nullptr, 1));
-        } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !getenv("MI3D_FORCE_DIRECT") &&
-                   !getenv("MI3D_NO_C1_MFMA")) {
+        } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !mi3d_routes().force_direct &&
+                   !mi3d_routes().no_c1_mfma) {
             MI3D_TRY(conv3_c1_fwd_mfma((const float*)in, c.P(H.pidx), fbias, zo, zocs, H.Cout, g, nullptr, c.s, scale, 1));
         } else {
             MI3D_TRY(conv3_direct_pack(c.P(H.pidx), H.Cin, H.Cout, c.at<float>(H.wpf), nullptr, c.s, scale));
@@ -441,7 +505,7 @@ int block_infer(const Ctx& c, int b, const float* x) {
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 3; }
+int mi3d_abi_version(void) { return 4; }
 
 int mi3d_unet_num_params(const mi3d_unet_desc* d) { return d ? 8 * (2 * d->n_levels + 1) + 2 * d->n_levels + 2 : -1; }
 int mi3d_unet_num_buffers(const mi3d_unet_desc* d) { return d ? 6 * (2 * d->n_levels + 1) : -1; }
@@ -521,7 +585,7 @@ static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void
     for (int l = 0; l < L; l++) {
         // fused apply + pool: even sides (every voxel in exactly one window) and 32-bit element indices
         const bool even = p.geo[l].D % 2 == 0 && p.geo[l].H % 2 == 0 && p.geo[l].W % 2 == 0 &&
-                          p.geo[l].M() * p.C[l] < (1ll << 31) && !getenv("MI3D_NO_POOL_FUSE");
+                          p.geo[l].M() * p.C[l] < (1ll << 31) && !mi3d_routes().no_pool_fuse;
         MI3D_TRY(block_forward(c, l, x, buffers, drop_scales, training, even ? c.at(p.pool[l]) : nullptr, p.C[l]));
         if (!even) MI3D_TRY(maxpool2_fwd(p.dt, c.at(p.cat[l]), p.catcs(l), p.C[l], p.geo[l], c.at(p.pool[l]), p.C[l], c.s));
     }
@@ -688,7 +752,7 @@ int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* 
 static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                        const float* drop_scales, const float* dlogits_in, const float* dgap, float gap_scale, int accumulate,
                        int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
-                       void* const* events, const HeadLoss* hl) {
+                       void* const* events, int aux_join, const HeadLoss* hl) {
     Plan p;
     MI3D_TRY(build_plan(d, p));
     MI3D_CHECK_ARG(x && params && grads && workspace, "mi3d_unet_backward: null pointer");
@@ -701,7 +765,7 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
     Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
     if (aux_stream && events) { c.s2 = (hipStream_t)aux_stream; c.ev = (hipEvent_t*)events; }
     float* wgws = c.at<float>(p.wgws);
-    c.defer_slabs = !getenv("MI3D_NO_PEND_SLABS");
+    c.defer_slabs = !mi3d_routes().no_pend_slabs;
     auto G = [&](int i) { return (float*)grads[i]; };
     for (int seg = seg_begin; seg < seg_end; seg++) {
         if (seg == 0) {
@@ -735,7 +799,7 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
             // the decoder conv's pending slab sum (it reads wgws) stays pending across the transposed conv's backward, which
             // therefore writes its slabs to the second workspace; the next BatchNorm-backward reduction carries both sums: one
             // chain link less per level (not with the two-stream weight gradients, which own that workspace)
-            const bool keep = p.up_mfma[i] && c.has_pend && !c.has_pend2 && c.defer_slabs && !c.s2 && !getenv("MI3D_NO_UPBWD_CARRY");
+            const bool keep = p.up_mfma[i] && c.has_pend && !c.has_pend2 && c.defer_slabs && !mi3d_routes().no_upbwd_carry;
             if (p.up_mfma[i] && keep) {
                 c.pend2 = SlabJob();
                 MI3D_TRY(upconv2_mfma_bwd(uin, 2 * p.C[l], 2 * p.C[l], gup, gupcs, p.C[l],
@@ -767,9 +831,16 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
         }
     }
     MI3D_TRY(c.flush_pend());
-    // join: everything the aux stream produced is ordered before whatever the caller enqueues next on `stream`
-    for (int i = 0; i < 2; i++)
-        if (c.rec[i]) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[2 + i], 0));
+    // weight gradients still queued (a call that ends before the group's own fork point): they go out now, so that every
+    // gradient of the segments [seg_begin, seg_end) is at least in flight when the call returns
+    if (c.s2 && c.ev) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+    if (c.aux_used) {
+        // event 3 = "the aux stream has finished what this call gave it".  aux_join: the compute stream waits for it here, i.e.
+        // everything is ordered before whatever the caller enqueues next on `stream`; otherwise the CALLER orders its consumers
+        // (optimizer, gradient exchange, the end of a graph capture) after event 3 / the aux stream
+        MI3D_HIP(hipEventRecord(c.ev[3], c.s2));
+        if (aux_join) MI3D_HIP(hipStreamWaitEvent(c.s, c.ev[3], 0));
+    }
     return 0;
 }
 
@@ -778,19 +849,20 @@ extern "C" {
 int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                        const float* drop_scales, const float* dlogits, const float* dgap, float gap_scale, int accumulate,
                        int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
-                       void* const* events) {
+                       void* const* events, int aux_join) {
     return unet_backward_impl(d, x, params, grads, drop_scales, dlogits, dgap, gap_scale, accumulate, seg_begin, seg_end, workspace,
-                              workspace_bytes, stream, aux_stream, events, nullptr);
+                              workspace_bytes, stream, aux_stream, events, aux_join, nullptr);
 }
 
 int mi3d_unet_backward_loss(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                             const float* drop_scales, const int64_t* labels, const float* teacher_logits, const mi3d_loss_cfg* cfg,
                             const float* coef, const float* grad_scale, const float* dgap, float gap_scale, int accumulate, int seg_begin,
-                            int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events) {
+                            int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream, void* const* events,
+                            int aux_join) {
     MI3D_CHECK_ARG(labels && cfg && coef, "mi3d_unet_backward_loss: null pointer");
     HeadLoss hl{labels, cfg_of(cfg), nullptr, const_cast<float*>(coef), nullptr, nullptr, nullptr, grad_scale, teacher_logits};
     return unet_backward_impl(d, x, params, grads, drop_scales, nullptr, dgap, gap_scale, accumulate, seg_begin, seg_end, workspace,
-                              workspace_bytes, stream, aux_stream, events, &hl);
+                              workspace_bytes, stream, aux_stream, events, aux_join, &hl);
 }
 
 }  // extern "C"

@@ -430,7 +430,7 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
     MI3D_CHECK_ARG(g.M() < (1ll << 31), "upconv2_mfma_bwd: more than 2^31 input voxels");
     const bf16* xp = (const bf16*)x; const bf16* gp = (const bf16*)gy;
     const bf16* wb = (const bf16*)wp + (size_t)Cin * Cout * 8;
-    if (dx && (dW || db) && !getenv("MI3D_NO_FUSED_UPBWD")) {
+    if (dx && (dW || db) && !mi3d_routes().no_fused_upbwd) {
         int gx = wave_grid(g.M());
         int gy = 1;
         while (gx * gy < 512 && gy < Cin / 16) gy *= 2;

@@ -139,7 +139,7 @@ class _UNetFn(torch.autograd.Function):
         hook = hold.segment_hook
         for seg in range(nseg):
             call("mi3d_unet_backward", C.byref(desc), ptr(x), ptab, gtab, ptr(ctx.drop), ptr(dlogits), ptr(dgap),
-                 1.0, 0, seg, seg + 1, ptr(ctx.ws), hold.ws_bytes, stream_ptr(), None, None)
+                 1.0, 0, seg, seg + 1, ptr(ctx.ws), hold.ws_bytes, stream_ptr(), None, None, 1)
             if hook is not None:
                 hook(seg, grads)
         ctx.ws = None

@@ -194,6 +194,9 @@ class _StepBase:
         compute stream keeps going."""
         cs = self.comm_stream
         cs.wait_stream(torch.cuda.current_stream())
+        aux = getattr(self, "aux_stream", None)
+        if aux is not None:        # gradients the deferred weight-gradient kernels are still writing (TrainStep aux_wgrad)
+            cs.wait_stream(aux)
         with torch.cuda.stream(cs):
             fn()
 
@@ -298,9 +301,12 @@ class _StepBase:
 class TrainStep(_StepBase):
     def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
                  grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
-                 compute_dtype=None, use_graph=False, two_stream=False, reference_zero_grad_quirk=False,
+                 compute_dtype=None, use_graph=False, aux_wgrad=True, reference_zero_grad_quirk=False,
                  force_comm=False, overlap_teacher=True, keep_logits=False):
-        """keep_logits: the step folds the 1x1x1 head into the loss and never writes the logits (mi3d_unet_forward_loss); True
+        """aux_wgrad: the backward's critical path is the input-gradient chain alone -- the weight gradients of the decoder's
+        full-resolution convs and of all deep-level convs run on a second stream (include/mi3d.h, mi3d_unet_backward: aux_stream),
+        forked from the chain at most three times and joined in front of the optimizer; bit-identical results.
+        keep_logits: the step folds the 1x1x1 head into the loss and never writes the logits (mi3d_unet_forward_loss); True
         keeps a copy in the static buffer `logits` for callers that read them after step().
         reference_zero_grad_quirk: train_unet.py:222 / finetune_ct.py:161 call optimizer.zero_grad() INSIDE
         accelerator.accumulate(), where accelerate only really zeroes on the boundary micro-step -> the gradient the
@@ -324,11 +330,11 @@ class TrainStep(_StepBase):
         # branches are captured into the one step graph).  Separate workspaces and logits: results are bitwise those of the
         # serial order.  Both forwards are long chains that leave most CUs idle at the deep levels, so they interleave.
         self.kd_stream = concurrent_stream(self.device) if (kd_teacher is not None and overlap_teacher) else None
-        # second compute stream: weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
-        self.aux_stream = concurrent_stream(self.device) if two_stream else None
+        # second compute stream: the deferred weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
+        self.aux_stream = concurrent_stream(self.device) if aux_wgrad else None
         self._events = None
         self._event_handles = []
-        if two_stream:
+        if aux_wgrad:
             for _ in range(4):
                 e = C.c_void_p()
                 call("mi3d_event_create", C.byref(e))
@@ -406,7 +412,7 @@ class TrainStep(_StepBase):
         st["btab"] = ptr_table([b.data_ptr() for b in self.model.buffers()])
         if mode == "train":
             st["dlogits"] = torch.empty_like(st["logits"])
-            st["fused_head"] = (not os.environ.get("MI3D_NO_HEAD_LOSS") and
+            st["fused_head"] = (not _lib.get_route("no_head_loss") and
                                 lib.mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.cfg)) == 1)
             st["ndrop"] = lib.mi3d_unet_dropout_count(C.byref(desc))
             st["drop"] = torch.empty(st["ndrop"], dtype=torch.float32, device=dev)
@@ -517,6 +523,7 @@ class TrainStep(_StepBase):
             nseg = st["nseg_run"]
             do_comm = self.do_comm and boundary
             aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
+            aux_open = False        # aux-stream work of an earlier call that nothing on the compute stream has waited for yet
             # one C call per run of segments between exchange steps: kernels of adjacent segments share launches (a
             # weight-gradient slab sum rides in the next BatchNorm reduction), which a call boundary would cut
             start = 0
@@ -530,14 +537,20 @@ class TrainStep(_StepBase):
                 if last or exch:
                     if budget and in_flight:
                         call("mi3d_set_cu_budget", budget)
+                    # the compute stream joins the aux stream at the end of the LAST call only (in front of the optimizer); a call
+                    # that is followed by a gradient exchange leaves the join to the exchange stream (_on_comm_stream), so the
+                    # deep-level weight gradients keep running under the next segments.  Segmented graphs end a capture at every
+                    # exchange: there every call joins
+                    join = 1 if (last or self.use_graph or aux is None) else 0
+                    aux_open = aux_open or (aux is not None and not join)
                     if fused:
                         call("mi3d_unet_backward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
                              ptr(st["y"]), ptr(t_logits), C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), None, 1.0,
-                             accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux, self._events)
+                             accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux, self._events, join)
                     else:
                         call("mi3d_unet_backward", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
                              ptr(st["dlogits"]), None, 1.0, accumulate, start, seg + 1, ptr(st["ws"]), st["ws_bytes"], s, aux,
-                             self._events)
+                             self._events, join)
                     if budget and in_flight:
                         call("mi3d_set_cu_budget", 0)
                     in_flight = in_flight or bool(exch)
@@ -555,6 +568,8 @@ class TrainStep(_StepBase):
                         comm(self._join_comm)
                         comm(lambda b=tuple(exch), wm=with_met: ([self.comm.average_(met)] if wm else []) +
                              [self.comm.reduce_bucket(k) for k in b])
+            if aux_open:       # the last call may have had nothing for the aux stream: join what earlier calls left there
+                torch.cuda.current_stream().wait_stream(self.aux_stream)
         if met_pending:
             comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
         if self.do_comm and not joined:
@@ -600,7 +615,7 @@ class TrainStep(_StepBase):
         desc = st["desc"]
         s = stream_ptr()
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
-        fused = (not os.environ.get("MI3D_NO_HEAD_LOSS") and not self.keep_logits and
+        fused = (not _lib.get_route("no_head_loss") and not self.keep_logits and
                  _lib.lib().mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.eval_cfg)) == 1)
         if fused:       # head + loss + metrics on the decoder output: the validation logits are never written either
             call("mi3d_unet_infer", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], None, None,
@@ -709,7 +724,7 @@ class DannStep(_StepBase):
         st["y"] = torch.empty((n, desc.D * desc.H * desc.W), dtype=torch.int64, device=dev)
         st["logits"] = torch.empty((n, c, desc.D, desc.H, desc.W), dtype=torch.float32, device=dev)
         st["dlogits"] = torch.empty_like(st["logits"])
-        st["fused_head"] = (not os.environ.get("MI3D_NO_HEAD_LOSS") and
+        st["fused_head"] = (not _lib.get_route("no_head_loss") and
                             lib.mi3d_unet_head_loss_supported(C.byref(desc), C.byref(self.cfg)) == 1)
         st["coef"] = torch.empty(_lib.LOSS_COEF_FLOATS, dtype=torch.float32, device=dev)
         st["loss_ws"] = torch.empty(lib.mi3d_seg_loss_workspace_bytes(c), dtype=torch.uint8, device=dev)
@@ -842,14 +857,14 @@ class DannStep(_StepBase):
                 if fused:
                     call("mi3d_unet_backward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s), ptr(st["y"]),
                          None, C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), dgs, -lam, accumulate, start, sg + 1,
-                         ptr(st["ws_s"]), st["ws_bytes"], s, None, None)
+                         ptr(st["ws_s"]), st["ws_bytes"], s, None, None, 1)
                 else:
                     call("mi3d_unet_backward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["gtab"], ptr(drop_s),
-                         ptr(st["dlogits"]), dgs, -lam, accumulate, start, sg + 1, ptr(st["ws_s"]), st["ws_bytes"], s, None, None)
+                         ptr(st["dlogits"]), dgs, -lam, accumulate, start, sg + 1, ptr(st["ws_s"]), st["ws_bytes"], s, None, None, 1)
                 t0 = max(start, L + 1)            # the target graph has no decoder part
                 if sg + 1 > t0:
                     call("mi3d_unet_backward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["gtab"], ptr(drop_t),
-                         None, dgt, -lam, 1, t0, sg + 1, ptr(st["ws_t"]), st["ws_bytes"], s, None, None)
+                         None, dgt, -lam, 1, t0, sg + 1, ptr(st["ws_t"]), st["ws_bytes"], s, None, None, 1)
                 start = sg + 1
                 if exch:
                     comm(lambda k=sg: self._on_comm_stream(lambda: self.comm.reduce_bucket(k)))

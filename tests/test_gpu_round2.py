@@ -152,7 +152,7 @@ def test_dropout_reference_masks_default_net(golden, dtype):
 
 
 @pytest.mark.parametrize("dtype,size", [(torch.float32, 16), (torch.bfloat16, 32)])
-def test_dropout_random_masks_vs_oracle(dtype, size, monkeypatch):
+def test_dropout_random_masks_vs_oracle(dtype, size, routes):
     """N=2, p=0.5 masks that differ between the two samples (the per-sample index row/V of bn.hip), whole net forward
     + backward vs oracle/torch_ref with the same masks; bf16 at 32^3 runs the planar full-resolution layout and must be
     bitwise equal with the layout switched off; channels dropped in BOTH samples must have exactly-zero gradients."""
@@ -220,7 +220,7 @@ def test_dropout_random_masks_vs_oracle(dtype, size, monkeypatch):
                 gsel = grads[name][dead]
                 assert float(gsel.abs().max()) == 0.0, (name, float(gsel.abs().max()))
     if not fp32:
-        monkeypatch.setenv("MI3D_NO_PLANAR", "1")
+        routes.set("no_planar", 1)
         o2, l2, g2 = run()
         assert l2 == l and torch.equal(o2, o)
         for k in grads:
@@ -746,7 +746,7 @@ def test_upconv_backward_exact(orc, shape):
     np.testing.assert_allclose(db.cpu().numpy(), rgb, rtol=0, atol=1e-5)
 
 
-def test_fused_backward_route_is_exactly_the_unfused_one_at_scale(monkeypatch):
+def test_fused_backward_route_is_exactly_the_unfused_one_at_scale(routes):
     """Headline shape (96^3, N=2, bf16): the fused launches (conv3_bwd_fused_*, upconv_mfma_bwd_fused_kernel) against the
     stand-alone kernels on the same data.  The input-gradient bodies are identical -> every gradient that depends only
     on data gradients and BN sums through them is compared per tensor (not concatenated) with the tolerance of a
@@ -765,8 +765,8 @@ def test_fused_backward_route_is_exactly_the_unfused_one_at_scale(monkeypatch):
         return l.item(), {k: p.grad.clone() for k, p in m.named_parameters()}
 
     l0, g0 = run()
-    monkeypatch.setenv("MI3D_NO_FUSED_BWD", "1")
-    monkeypatch.setenv("MI3D_NO_FUSED_UPBWD", "1")
+    routes.set("no_fused_bwd", 1)
+    routes.set("no_fused_upbwd", 1)
     l1, g1 = run()
     assert l0 == l1
     worst = 0.0

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib._SIGS, f"_lib.py does not bind {name}"
         assert len(_lib._SIGS[name][1]) == nargs, f"{name}: header has {nargs} args, binding {len(_lib._SIGS[name][1])}"
     assert set(_lib._SIGS) == set(fns)
-    assert lib.mi3d_abi_version() == 3
+    assert lib.mi3d_abi_version() == 4
 
 
 def test_state_dict_surface_matches_reference(golden):
@@ -219,3 +219,22 @@ def test_kernel_roofline_tool_assigns_every_launch_of_the_committed_timeline(tmp
     for row in rows:
         if row["kernel"].startswith(("conv3_", "upconv_", "head_loss")):
             assert float(row["algo_MB"]) > 0 and row["layer"], row
+
+
+def test_route_switches_are_read_once_and_set_through_the_abi():
+    """Every kernel-selection switch lives in one struct (csrc/common.h MI3D_ROUTE_LIST): the environment is read at first use
+    only, later changes go through mi3d_debug_set_route; unknown names fail loudly."""
+    import os
+    names = _lib.route_names()
+    assert "no_defer_wgrad" in names and "ks_target" in names and len(names) == len(set(names))
+    assert _lib.get_route("ks_target") == 128 and _lib.get_route("conv8") == 1
+    os.environ["MI3D_NO_PERSIST"] = "1"          # after the first use: ignored
+    try:
+        assert _lib.get_route("no_persist") == 0
+    finally:
+        del os.environ["MI3D_NO_PERSIST"]
+    with _lib.routes(no_persist=1, ks_target=64):
+        assert _lib.get_route("no_persist") == 1 and _lib.get_route("ks_target") == 64
+    assert _lib.get_route("no_persist") == 0 and _lib.get_route("ks_target") == 128
+    with pytest.raises(_lib.Mi3dError):
+        _lib.set_route("no_such_route", 1)
