@@ -79,15 +79,15 @@ def cpu_baseline(size, batch, max_seconds=24.0):
             "sample": f"{runs[best][1]} fwd+loss+bwd steps of UNet3D {size}^3 N={batch} fp32 after 1 warm-up (median), per thread count"}
 
 
-def _kernel_traffic(kernel_substr, ms):
-    """HBM bytes per launch of the named kernel from the committed PMC passes of this build (tools/collect_profiles.sh ->
+def _kernel_traffic(key, ms):
+    """HBM bytes per launch of a roofline candidate from the committed PMC passes of this build (tools/collect_profiles.sh ->
     profiles/roofline_kernel_traffic.json: FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of the whole step,
     corrected by tools/pmc_traffic.py).  A PMC pass cannot run inside this process; the committed value is reported only
     while the kernel still takes the time it took when the counters were collected (else null, not a stale number)."""
     tf = os.path.join(ROOT, "profiles", "roofline_kernel_traffic.json")
     try:
-        rec = json.load(open(tf))
-        if kernel_substr not in rec.get("kernel", ""):
+        rec = json.load(open(tf)).get("records", {}).get(key)
+        if not rec:
             return None
         ref_ms = rec.get("ms_per_launch_when_measured")
         if ref_ms and abs(ms - ref_ms) > 0.10 * ref_ms:
@@ -97,65 +97,118 @@ def _kernel_traffic(kernel_substr, ms):
         return None
 
 
+def roofline_candidates(size, batch):
+    """The full-resolution conv launches of one step that can be the largest one, keyed on the LAYER (hook kinds: include/mi3d.h,
+    mi3d_time_next_conv3_kernel).  Algorithmic bytes per launch = every operand of that launch once (bf16 activations, fp32 dW):
+    weight gradient R x, R dy, W dW; input gradient / forward R in, W out; fused backward R dy, R x, W dx, W dW (both products of
+    the layer share one read of dy in the ideal kernel).  `ordinal` = which dispatch of that kernel name inside one step
+    (tools/collect_profiles.sh picks the PMC record with it)."""
+    vox = batch * size ** 3
+    c = []
+
+    def add(key, kind, cin, cout, kernel, ordinal, layer, elems, flops_mul):
+        c.append({"key": key, "kind": kind, "cin": cin, "cout": cout, "kernel": kernel, "ordinal": ordinal, "layer": layer,
+                  "bytes": vox * elems * 2 + (16 * 32 * 27 * 4 if kind in (0, 1) else 0), "flops": flops_mul * 27 * 32 * 16 * vox})
+    add("wgrad_dec3_conv0", 1, 32, 16, "conv3_wgrad_mfma_kernel<1, 1, 27>", 1,
+        "decoder.3.conv0 weight gradient (32->16 at full resolution; on the aux stream beside the deep-level chain)", 32 + 16, 2)
+    add("dgrad_dec3_conv0", 3, 16, 32, "conv3_mfma_persist_kernel<2, 1, false>", 0,
+        "decoder.3.conv0 input gradient (conv 16->32 at full resolution)", 16 + 32, 2)
+    add("fwd_dec3_conv0", 2, 32, 16, "conv3_mfma_persist_kernel<1, 2, true>", 0,
+        "decoder.3.conv0 forward (conv 32->16 at full resolution, BatchNorm partial sums fused)", 32 + 16, 2)
+    add("bwd_dec3_conv0_fused", 0, 32, 16, "conv3_bwd_fused_persist_kernel<2, 1>", 0,
+        "decoder.3.conv0 backward, input + weight gradient in one launch (single-stream route only)", 16 + 32 + 32, 4)
+    c.append({"key": "bwd_enc0_conv1_fused", "kind": 0, "cin": 16, "cout": 16, "kernel": "conv3_bwd_fused_persist_kernel<1, 1>",
+              "ordinal": 0, "layer": "encoder.0.conv1 backward, input + weight gradient in one launch (16->16 at full resolution)",
+              "bytes": vox * 48 * 2 + 16 * 16 * 27 * 4, "flops": 4 * 27 * 16 * 16 * vox})
+    return c
+
+
+def _time_hooked(once, kind, cin, cout, iters):
+    """ms per launch of the armed kernel inside `once()` (HIP events tightly around the kernel on ITS stream), or None when
+    no launch of that kind / layer happens in it."""
+    import ctypes as C
+    from multimodal_segmentation_project_amd import _lib
+    from multimodal_segmentation_project_amd._lib import call
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    call("mi3d_timing_event_create", C.byref(e0))
+    call("mi3d_timing_event_create", C.byref(e1))
+    tot, n = 0.0, 0
+    try:
+        for _ in range(iters):
+            call("mi3d_time_next_conv3_kernel", e0, e1, kind, cin, cout)
+            once()
+            if _lib.lib().mi3d_time_hook_fired() != 1:       # also disarms: the events are never left armed
+                return None
+            torch.cuda.synchronize()
+            t = C.c_float()
+            call("mi3d_event_elapsed_ms", e0, e1, C.byref(t))
+            tot += t.value
+            n += 1
+    finally:
+        _lib.lib().mi3d_time_hook_fired()
+        call("mi3d_event_destroy", e0)
+        call("mi3d_event_destroy", e1)
+    return tot / n if n else None
+
+
 def roofline_dominant(size, batch, dtype_code, iters=10, ts=None):
-    """Dominant kernel = the launch with the largest time per step (profiles/rNN_step_timeline.txt): the fused backward of
-    decoder.3.conv0 (32 -> 16 channels at full resolution), conv3_bwd_fused_persist_kernel<2,1> = input gradient + weight
-    gradient of the layer in one launch.  Timed live with HIP events recorded tightly around THAT kernel on the stream it is
-    launched on (mi3d_time_next_conv3_bwd_kernel), inside real training steps when the TrainStep `ts` is given (the kernel
-    with the step's own data and layout: the skip/up halves of the concat buffer are two planes there), else inside the
-    per-operator call.  Algorithmic bytes per launch = read dy once + read x once + write dx once (+ dW):
-    M * (Cout + Cin + Cin) * 2 B -- both products of the layer share one read of dy in the ideal kernel."""
+    """Dominant kernel = the launch with the largest time in one step, CHOSEN BY MEASUREMENT among the full-resolution conv
+    launches (roofline_candidates): each is timed live with HIP events recorded tightly around THAT kernel on the stream it is
+    launched on, inside real training steps of the TrainStep `ts` (the kernel with the step's own data, layout and neighbours:
+    a weight gradient on the aux stream is timed while the chain's kernels run beside it).  The others are reported in
+    `others`.  Without `ts` (exact fp32 path, other workloads): the per-operator backward call of the 32->16 layer."""
     import ctypes as C
     from multimodal_segmentation_project_amd import _lib
     from multimodal_segmentation_project_amd._lib import call, ptr, stream_ptr
     dev = "cuda"
+    n, d = batch, size
+    if ts is not None and dtype_code == 1:
+        was = ts.use_graph
+        ts.use_graph = False                   # eager launches: the hook needs the launch to happen in this call
+        for _ in range(2):
+            ts.step_static()
+        rows = []
+        for cd in roofline_candidates(size, batch):
+            ms = _time_hooked(ts.step_static, cd["kind"], cd["cin"], cd["cout"], iters)
+            if ms is None:
+                continue
+            ach = cd["bytes"] / (ms * 1e-3) / 1e9
+            rows.append({"bound": "hbm", "kernel": cd["kernel"] + " = " + cd["layer"], "key": cd["key"], "measured": "inside training steps",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": _kernel_traffic(cd["key"], ms), "traffic_source": "profiles/roofline_kernel_traffic.json (PMC passes "
+                         "of this build; null when the live time is off by > 10 % from the time the counters were collected at)",
+                         "ms_per_launch": ms, "algorithmic_bytes_per_launch": cd["bytes"], "flops_per_launch": cd["flops"]})
+        ts.use_graph = was
+        if not rows:
+            return None
+        rows.sort(key=lambda r: -r["ms_per_launch"])
+        top = rows[0]
+        top["others"] = [{k: r[k] for k in ("key", "kernel", "ms_per_launch", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch")}
+                         for r in rows[1:]]
+        return top
     cin, cout = 32, 16
     esz = 2 if dtype_code == 1 else 4
     T = torch.bfloat16 if dtype_code == 1 else torch.float32
-    n, d = batch, size
     vox = n * d ** 3
     algo_bytes = vox * (cout + cin + cin) * esz + cout * cin * 27 * 4
-    kernel = "conv3_bwd_fused_persist_kernel<2, 1>"
-    in_step = ts is not None and dtype_code == 1 and d % 16 == 0 and d >= 32
-    if not in_step:
-        x = torch.randn((n, d, d, d, cin), device=dev).to(T)
-        dy = torch.randn((n, d, d, d, cout), device=dev).to(T)
-        w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
-        dx = torch.empty_like(x)
-        dW, db = torch.empty_like(w), torch.empty(cout, device=dev)
-        wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, d, d)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        s = stream_ptr()
+    x = torch.randn((n, d, d, d, cin), device=dev).to(T)
+    dy = torch.randn((n, d, d, d, cout), device=dev).to(T)
+    w = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
+    dx = torch.empty_like(x)
+    dW, db = torch.empty_like(w), torch.empty(cout, device=dev)
+    wsb = _lib.lib().mi3d_conv3_workspace_bytes(cin, cout, n, d, d, d)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    s = stream_ptr()
 
-        def once():
-            call("mi3d_conv3_backward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(dy), cout, cout, ptr(dx), cin, ptr(dW),
-                 ptr(db), 0, n, d, d, d, ptr(ws), wsb, s)
-        skip = 0
-    else:
-        was = ts.use_graph
-        ts.use_graph = False                   # eager launches: the hook needs the launch to happen in this call
-
-        def once():
-            ts.step_static()
-        skip = 1                               # backward launch order: decoder.3.conv1 (<1,1>), then decoder.3.conv0 (<2,1>)
+    def once():
+        call("mi3d_conv3_backward", dtype_code, dtype_code, ptr(x), cin, cin, ptr(w), ptr(dy), cout, cout, ptr(dx), cin, ptr(dW),
+             ptr(db), 0, n, d, d, d, ptr(ws), wsb, s)
     for _ in range(2):
         once()
-    if dtype_code == 1:
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        call("mi3d_timing_event_create", C.byref(e0))
-        call("mi3d_timing_event_create", C.byref(e1))
-        tot = 0.0
-        for _ in range(iters):
-            call("mi3d_time_next_conv3_bwd_kernel", e0, e1, skip)
-            once()
-            t = C.c_float()
-            call("mi3d_event_elapsed_ms", e0, e1, C.byref(t))
-            tot += t.value
-        ms = tot / iters
-        call("mi3d_event_destroy", e0)
-        call("mi3d_event_destroy", e1)
-    else:       # exact fp32 path: separate direct kernels, the whole operator call is timed
-        kernel = "conv3 direct dgrad + wgrad (fp32 path, whole operator call)"
+    kernel = "conv3_bwd_fused_persist_kernel<2, 1> = conv3 backward 32->16 (input + weight gradient in one launch)"
+    ms = _time_hooked(once, 0, cin, cout, iters) if dtype_code == 1 else None
+    if ms is None:      # exact fp32 path / shapes without the persistent kernels: the whole operator call is timed
+        kernel = "conv3 backward 32->16, whole operator call (" + ("fp32 direct kernels" if dtype_code == 0 else "generic kernels") + ")"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
@@ -163,13 +216,10 @@ def roofline_dominant(size, batch, dtype_code, iters=10, ts=None):
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / iters
-    if in_step:
-        ts.use_graph = was
     achieved = algo_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": kernel + " = conv3 bwd 32->16 (decoder.3.conv0: input gradient + weight gradient)",
-            "measured": "inside training steps" if in_step else "per-operator call",
+    return {"bound": "hbm", "kernel": kernel, "measured": "per-operator call",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": _kernel_traffic(kernel, ms), "ms_per_launch": ms, "algorithmic_bytes_per_launch": algo_bytes,
+            "traffic": None, "ms_per_launch": ms, "algorithmic_bytes_per_launch": algo_bytes,
             "flops_per_launch": 2 * 2 * 27 * cin * cout * vox}
 
 
@@ -229,6 +279,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-aux-wgrad", action="store_true",
                     help="keep every weight gradient on the data-gradient chain (default: the decoder / deep-level ones run on a second stream)")
+    ap.add_argument("--chain-prio", default=os.environ.get("MI3D_BENCH_CHAIN_PRIO", "normal"), choices=["normal", "high"],
+                    help="priority class of the stream the step runs on (the aux stream of the weight gradients has the lowest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sclk", action="store_true",
@@ -265,6 +317,8 @@ def main():
     import multimodal_segmentation_project_amd as mi
     from multimodal_segmentation_project_amd.trainer import TrainStep
 
+    if a.chain_prio == "high":
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     if a.roofline_only:
         print(json.dumps(roofline_dominant(a.size, a.batch, 1 if a.dtype == "bf16" else 0, iters=a.steps)))
         return

@@ -110,6 +110,11 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
  * for events[3] / aux_stream.  Results are bit-identical to the single-stream route. */
 int mi3d_event_create(void** event_out);
 int mi3d_event_destroy(void* event);
+/* A non-blocking hipStream_t of a priority class: -1 = the device's highest, 0 = middle, +1 = lowest.  torch.cuda.Stream only
+ * offers high / normal; the aux stream of the deferred weight gradients wants the LOWEST class, so that the wave dispatcher
+ * gives a free workgroup slot to the data-gradient chain first.  The caller owns the stream (mi3d_stream_destroy). */
+int mi3d_stream_create(int priority_class, void** stream_out);
+int mi3d_stream_destroy(void* stream);
 /* Route switches: every kernel-selection switch of the library ("no_persist", "no_fused_bwd", "ks_target", ... -- the table
  * in INTEGRATION.md) is read from the environment (MI3D_<NAME>=<int>) ONCE, when the library is first used; afterwards only
  * these calls change one.  Debug / test interface: do not call it concurrently with launches; a captured hipGraph keeps the
@@ -119,10 +124,15 @@ int mi3d_debug_get_route(const char* name, int* value_out);
 int mi3d_debug_route_count(void);
 int mi3d_debug_experiments(void);      /* 1: built with make EXPERIMENTS=1 (default-off experiment kernels compiled in) */
 const char* mi3d_debug_route_name(int index);
-/* Measurement hooks (bench.py `roofline`: HIP events around ONE kernel on the stream it is launched on).
- * mi3d_time_next_conv3_bwd_kernel: the (skip+1)-th full-resolution fused conv backward launch from now (mi3d_conv3_backward /
- * mi3d_unet_backward on the calling thread; in the backward of a UNet3D step launch 0 is decoder.L-1.conv1, launch 1
- * decoder.L-1.conv0) records start/stop -- timing events from mi3d_timing_event_create -- tightly around its kernel; one-shot.
+/* Measurement hook (bench.py `roofline`: HIP events around ONE kernel on the stream it is launched on, also the aux stream).
+ * mi3d_time_next_conv3_kernel arms it for the calling thread: the next launch of `kind` for the layer (Cin, Cout as that
+ * launcher sees them) records start/stop -- timing events from mi3d_timing_event_create -- tightly around its kernel.
+ *   kind 0 = fused full-resolution conv backward (input + weight gradient in one launch; Cin, Cout of the layer)
+ *        1 = stand-alone conv weight gradient (Cin, Cout of the layer)
+ *        2 = persistent full-resolution conv with BatchNorm partial sums (the training forward; Cin, Cout of the conv)
+ *        3 = persistent full-resolution conv without (the input gradient: Cin = the layer's Cout, Cout = the layer's Cin)
+ * One-shot.  mi3d_time_hook_fired() returns 1 when the armed launch happened and disarms the hook either way (call it before
+ * reading the events: events that were never recorded cannot be waited for); NULL events disarm.
  * mi3d_event_elapsed_ms synchronises on `stop`. */
 /* mi3d_debug_occupy_cus: a stand-in for a resident collective kernel (RCCL all-reduce) on a 1-GPU box: `workgroups` x 512
  * threads x 128 VGPRs hold their CU slots for `microseconds` on `stream` and read through buf[0..n) meanwhile
@@ -132,7 +142,8 @@ int mi3d_debug_occupy_cus(int workgroups, int microseconds, float* buf, int64_t 
  * kernel that is resident beside them (TrainStep sets it for the backward segments that overlap a gradient exchange). */
 int mi3d_set_cu_budget(int cus);
 int mi3d_timing_event_create(void** event_out);
-int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event, int skip);
+int mi3d_time_next_conv3_kernel(void* start_event, void* stop_event, int kind, int Cin, int Cout);
+int mi3d_time_hook_fired(void);
 int mi3d_event_elapsed_ms(void* start_event, void* stop_event, float* ms_out);
 /* params-table index ranges whose gradients segment `seg` produces: ranges = {first0, last0, first1, last1}
  * (half-open; the second range is the segment's upconv for decoder segments, otherwise {-1,-1}) */

@@ -57,6 +57,8 @@ _SIGS = {
     "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp, i32]),
     "mi3d_event_create": (i32, [C.POINTER(vp)]),
     "mi3d_event_destroy": (i32, [vp]),
+    "mi3d_stream_create": (i32, [i32, C.POINTER(vp)]),
+    "mi3d_stream_destroy": (i32, [vp]),
     "mi3d_debug_set_route": (i32, [C.c_char_p, i32]),
     "mi3d_debug_get_route": (i32, [C.c_char_p, C.POINTER(C.c_int)]),
     "mi3d_debug_route_count": (i32, []),
@@ -65,7 +67,8 @@ _SIGS = {
     "mi3d_debug_occupy_cus": (i32, [i32, i32, vp, i64, vp]),
     "mi3d_set_cu_budget": (i32, [i32]),
     "mi3d_timing_event_create": (i32, [C.POINTER(vp)]),
-    "mi3d_time_next_conv3_bwd_kernel": (i32, [vp, vp, i32]),
+    "mi3d_time_next_conv3_kernel": (i32, [vp, vp, i32, i32, i32]),
+    "mi3d_time_hook_fired": (i32, []),
     "mi3d_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
     "mi3d_seg_loss_workspace_bytes": (sz, [i32]),
     "mi3d_seg_loss_forward": (i32, [vp, vp, vp, i32, i32, i64, _LP, vp, vp, vp, vp]),

@@ -356,6 +356,20 @@ int mi3d_event_create(void** event_out) {
     *event_out = (void*)e;
     return 0;
 }
+int mi3d_stream_create(int priority_class, void** stream_out) {
+    MI3D_CHECK_ARG(stream_out && priority_class >= -1 && priority_class <= 1, "mi3d_stream_create: bad arguments");
+    int least = 0, greatest = 0;      // numerically: least = lowest priority (largest value), greatest = highest
+    MI3D_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int prio = priority_class < 0 ? greatest : priority_class > 0 ? least : (least + greatest) / 2;
+    hipStream_t s;
+    MI3D_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+    *stream_out = (void*)s;
+    return 0;
+}
+int mi3d_stream_destroy(void* stream) {
+    if (stream) MI3D_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
 int mi3d_timing_event_create(void** event_out) {
     MI3D_CHECK_ARG(event_out, "mi3d_timing_event_create: null output");
     hipEvent_t e;

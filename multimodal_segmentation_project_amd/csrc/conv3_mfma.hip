@@ -1083,6 +1083,19 @@ inline int device_cus() {
     return n;
 }
 inline int persist_cus() { return device_cus() - g_cu_budget; }
+// ---- measurement hook (bench.py `roofline`): HIP events tightly around ONE kernel launch, keyed on the LAYER -----------------
+// kind 0 = fused full-resolution backward (input + weight gradient in one launch), 1 = stand-alone weight gradient,
+// 2 = persistent conv with BatchNorm partial sums (training forward), 3 = persistent conv without (input gradient);
+// cin / cout as the launcher sees them.  One-shot: the first matching launch of the calling thread takes the events.
+struct TimeHook { hipEvent_t e0 = nullptr, e1 = nullptr; int kind = -1, cin = 0, cout = 0; bool armed = false, fired = false; };
+static thread_local TimeHook g_hook;
+inline bool time_hook_take(int kind, int cin, int cout, hipEvent_t& e0, hipEvent_t& e1) {
+    if (!g_hook.armed || g_hook.kind != kind || g_hook.cin != cin || g_hook.cout != cout) return false;
+    e0 = g_hook.e0; e1 = g_hook.e1;
+    g_hook.armed = false; g_hook.fired = true;
+    return true;
+}
+
 inline bool persist_ok(int Cin, int Cout, Geo g) {
     // 16 -> 32 (two co blocks, 256 VGPRs): only worth it with >= 2 tiles per workgroup; the one-tile-per-workgroup
     // generic kernel is faster below that (level 1 of the 96^3 net)
@@ -1255,7 +1268,12 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         int tz = cdiv(g.D, 4), ty = cdiv(g.H, 8), tx = cdiv(g.W, 16), nt = g.N * tz * ty * tx, grid = persist_grid(Cin, Cout, g);
 #define PK(COB_, NCH_)                                                                                                         \
         do {                                                                                                                   \
-            if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu); \
+            hipEvent_t tev0 = nullptr, tev1 = nullptr;                                                                          \
+            if (time_hook_take(part ? 2 : 3, Cin, Cout, tev0, tev1)) {                                                          \
+                if (part) hipExtLaunchKernelGGL((conv3_mfma_persist_kernel<COB_, NCH_, true>), dim3(grid), dim3(BLK), 0, s, tev0, tev1, 0, xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu); \
+                else hipExtLaunchKernelGGL((conv3_mfma_persist_kernel<COB_, NCH_, false>), dim3(grid), dim3(BLK), 0, s, tev0, tev1, 0, xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, (float*)nullptr, xh, yh, relu); \
+            }                                                                                                                   \
+            else if (part) conv3_mfma_persist_kernel<COB_, NCH_, true><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu); \
             else conv3_mfma_persist_kernel<COB_, NCH_, false><<<grid, BLK, 0, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh, relu); \
         } while (0)
         // Cout = 16: asynchronous-staging variant (the tensor must be addressable with 32-bit byte offsets)
@@ -1930,8 +1948,13 @@ int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int 
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
     MI3D_SET_MAX_LDS_ONCE((&conv3_wgrad_mfma_kernel<CO_B, CI_B, NT>), lds);
     dim3 grid((unsigned)(c.nsb * c.tg), (unsigned)(Cout / (16 * CO_B)), (unsigned)(Cin / (16 * CI_B)));
-    conv3_wgrad_mfma_kernel<CO_B, CI_B, NT><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W,
-                                                                  cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh);
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    if (time_hook_take(1, Cin, Cout, tev0, tev1))
+        hipExtLaunchKernelGGL((conv3_wgrad_mfma_kernel<CO_B, CI_B, NT>), grid, dim3(BLK), lds, s, tev0, tev1, 0, x, xcs, Cin, dy, dycs, Cout,
+                              g.N, g.D, g.H, g.W, cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh);
+    else
+        conv3_wgrad_mfma_kernel<CO_B, CI_B, NT><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W,
+                                                                      cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1986,13 +2009,18 @@ int conv3_mfma_wgrad(const void* x, int xcs, int Cin, const void* dy, int dycs, 
     return wgrad_slab_sum(ws, c.nsb, Cin, Cout, dW, db, accumulate, s, pend);
 }
 
-static thread_local hipEvent_t g_time_ev[2] = {nullptr, nullptr};
-static thread_local int g_time_skip = 0;
-extern "C" int mi3d_time_next_conv3_bwd_kernel(void* start_event, void* stop_event, int skip) {
-    g_time_ev[0] = (hipEvent_t)start_event;
-    g_time_ev[1] = (hipEvent_t)stop_event;
-    g_time_skip = skip < 0 ? 0 : skip;
+
+extern "C" int mi3d_time_next_conv3_kernel(void* start_event, void* stop_event, int kind, int Cin, int Cout) {
+    g_hook = TimeHook();
+    if (!start_event || !stop_event) return 0;          // NULL events: disarm
+    g_hook.e0 = (hipEvent_t)start_event; g_hook.e1 = (hipEvent_t)stop_event;
+    g_hook.kind = kind; g_hook.cin = Cin; g_hook.cout = Cout; g_hook.armed = true;
     return 0;
+}
+extern "C" int mi3d_time_hook_fired(void) {             // 1: the armed launch happened (events recorded); always disarms
+    const int f = g_hook.fired ? 1 : 0;
+    g_hook = TimeHook();
+    return f;
 }
 
 // full-resolution layers: dgrad on the persistent body (Cout -> Cin must be one of its shapes)
@@ -2027,7 +2055,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     size_t ldsw = (size_t)(WNV + WNH) * 32;
     // measurement hook (mi3d_time_next_conv3_bwd_kernel): one-shot HIP events tightly around this kernel
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
-    if (g_time_ev[0] && g_time_skip-- == 0) { tev0 = g_time_ev[0]; tev1 = g_time_ev[1]; g_time_ev[0] = g_time_ev[1] = nullptr; }
+    time_hook_take(0, Cin, Cout, tev0, tev1);
 #define FP(COB_, NCH_)                                                                                                        \
     do {                                                                                                                      \
         size_t ldsp = (size_t)(6 * 10 * 18 * 16 + NCH_ * 14 * COB_ * 512) * 2 + 4 * COB_ * 16 * 2 * 4;                        \

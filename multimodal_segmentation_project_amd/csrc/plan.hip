@@ -219,7 +219,14 @@ struct Ctx {
     hipEvent_t* ev = nullptr;
     mutable int seq = 0;
     struct DJob { int b, h, wg_target; };
-    mutable DJob dq[4 * MAXL + 2];             // weight gradients whose dy is ready and that have not been launched yet
+    mutable DJob dq[4 * MAXL + 2];             // weight gradients whose dy is ready and that have not been forked yet
+    // forked (their event is recorded on the chain) but not yet ENQUEUED on the aux stream: the host enqueues them a few at a
+    // time between the chain's next launches (drain_aux).  A step is launched by ONE host thread, and at the end of the
+    // launch-bound deep-level chain it is barely ahead of the GPU: enqueueing the ten deep-level weight gradients and their slab
+    // sums in one go left the chain's queue empty for ~125 us (profiles/r04_defer_eager_streams_before.txt)
+    struct HJob { int b, h, wg_target, ev; };
+    mutable HJob hq[4 * MAXL + 2];
+    mutable int nhq = 0, hq_head = 0, waited_ev = -1;
     mutable int ndq = 0, nfork = 0;
     mutable bool aux_used = false;
     mutable bool packed = false;      // weight packs already done by the one-launch pack_all
@@ -344,28 +351,43 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
 // Launch the queued weight gradients on the aux stream, ordered after everything the compute stream has enqueued so far
 // (their dy buffers are complete).  They run one after the other there, each followed by its slab sum, sharing the third
 // slab workspace; nothing on the compute stream waits for them before the end of the step (unet_backward_impl joins).
-int flush_deferred(const Ctx& c, const float* x, void* const* grads, int accumulate) {
-    if (c.ndq == 0) return 0;
+// enqueue up to `n` forked weight gradients on the aux stream (n < 0: all).  Each runs after the fork event of its group, one
+// after the other there, followed by its slab sum, sharing the third slab workspace; nothing on the compute stream waits for
+// them before the end of the step (unet_backward_impl joins).
+int drain_aux(const Ctx& c, const float* x, void* const* grads, int accumulate, int n) {
     const Plan& p = c.p;
-    MI3D_CHECK_ARG(c.nfork < 3, "flush_deferred: more than three forks in one call");
-    hipEvent_t fe = c.ev[c.nfork++];
-    MI3D_HIP(hipEventRecord(fe, c.s));
-    MI3D_HIP(hipStreamWaitEvent(c.s2, fe, 0));
-    for (int q = 0; q < c.ndq; q++) {
-        int b = c.dq[q].b, h = c.dq[q].h;
-        const BlockP& B = p.blk[b];
-        const HalfP& H = B.h[h];
+    for (; c.hq_head < c.nhq && n != 0; c.hq_head++, n--) {
+        const Ctx::HJob& j = c.hq[c.hq_head];
+        if (j.ev != c.waited_ev) { MI3D_HIP(hipStreamWaitEvent(c.s2, c.ev[j.ev % 3], 0)); c.waited_ev = j.ev; }
+        const BlockP& B = p.blk[j.b];
+        const HalfP& H = B.h[j.h];
         Geo g = p.geo[B.level];
         const void* xin; int xcs, xdt;
-        block_input(c, b, x, xin, xcs, xdt);
-        const void* in = h == 0 ? xin : c.at(B.z1);
-        int ics = h == 0 ? xcs : H.Cout;
+        block_input(c, j.b, x, xin, xcs, xdt);
+        const void* in = j.h == 0 ? xin : c.at(B.z1);
+        int ics = j.h == 0 ? xcs : H.Cout;
         MI3D_TRY(conv3_mfma_wgrad(in, ics, H.Cin, c.at(H.dyk), H.Cout, H.Cout, g, (float*)grads[H.pidx], (float*)grads[H.pidx + 1], accumulate,
-                                  c.at<float>(p.wgws3), p.wgws_floats, c.s2, (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), nullptr,
-                                  c.dq[q].wg_target));
+                                  c.at<float>(p.wgws3), p.wgws_floats, c.s2, (j.h == 0 && j.b > p.L) ? p.halves(B.level) : Halves(), nullptr,
+                                  j.wg_target));
+        c.aux_used = true;
     }
+    if (c.hq_head == c.nhq) c.hq_head = c.nhq = 0;
+    return 0;
+}
+
+// Fork: the queued weight gradients may start once everything the compute stream has enqueued so far is done (their dy
+// buffers are complete).  lazy: only the event is recorded here, the launches are enqueued by later drain_aux calls.
+int flush_deferred(const Ctx& c, const float* x, void* const* grads, int accumulate, bool lazy = false) {
+    if (c.ndq == 0) return 0;
+    MI3D_CHECK_ARG(c.nfork < 3 || mi3d_routes().defer_fork_each, "flush_deferred: more than three forks in one call");
+    // (fork_each: the three fork events are re-recorded in turn; a stream wait keeps the record it was issued after -- so
+    // everything forked earlier is enqueued first)
+    if (c.nfork >= 3) MI3D_TRY(drain_aux(c, x, grads, accumulate, -1));
+    const int e = c.nfork++;
+    MI3D_HIP(hipEventRecord(c.ev[e % 3], c.s));
+    for (int q = 0; q < c.ndq; q++) c.hq[c.nhq++] = Ctx::HJob{c.dq[q].b, c.dq[q].h, c.dq[q].wg_target, e};
     c.ndq = 0;
-    c.aux_used = true;
+    if (!lazy) MI3D_TRY(drain_aux(c, x, grads, accumulate, -1));
     return 0;
 }
 
@@ -384,8 +406,10 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
     for (int h = 1; h >= 0; h--) {
         const HalfP& H = B.h[h];
         int k = c.seq++;
+        if (aux && c.nhq) MI3D_TRY(drain_aux(c, x, grads, accumulate, mi3d_routes().aux_drain));      // feed the aux stream between the chain's launches
         // deferred weight gradient: dy goes to the layer's own buffer, which nobody overwrites before the aux stream has read it
-        const bool dfr = aux && H.defer && (G(H.pidx) || G(H.pidx + 1));
+        const int dbit = H.defer == 2 ? 4 : (B.level == 0 ? 1 : 2);
+        const bool dfr = aux && H.defer && (mi3d_routes().defer_mask & dbit) && (G(H.pidx) || G(H.pidx + 1));
         void* dyb = dfr ? c.at(H.dyk) : c.at((k & 1) ? p.sB2 : p.sB);
         const void* dz = h == 1 ? dz2 : c.at(p.sC);
         int dcs = h == 1 ? dzcs : H.Cout;
@@ -403,9 +427,20 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             // the chain runs the input-gradient conv alone; the weight gradient is queued for the aux stream.  Its slab partition
             // is the fused launch's (conv3_mfma_bwd_wg_target), the input gradient uses the fused launch's split-K factor and the
             // same K order: both routes produce the same bits
-            c.dq[c.ndq++] = Ctx::DJob{b, h, conv3_mfma_bwd_wg_target(H.Cin, H.Cout, ics, H.Cout, dx_f ? dxs_f : 8, g)};
+            const int awt = mi3d_routes().aux_wg_target;
+            c.dq[c.ndq++] = Ctx::DJob{b, h, awt > 0 ? awt : conv3_mfma_bwd_wg_target(H.Cin, H.Cout, ics, H.Cout, dx_f ? dxs_f : 8, g)};
+        }
+        // fork points: what is queued goes to the aux stream when the chain has finished the BatchNorm backward of the last layer
+        // of a group (whether or not that very layer is deferred under the current defer_mask)
+        if (aux) {
+            if (mi3d_routes().defer_fork_each) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+            // group 1 forks when the GPU is still busy with the full-resolution decoder (the host is far ahead: enqueue at once);
+            // group 2 forks at the end of the launch-bound deep chain: its launches are fed in between the chain's next ones
             for (int q = 0; q < 2; q++)
-                if (b == p.flush_b[q] && h == p.flush_h[q]) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+                if (b == p.flush_b[q] && h == p.flush_h[q])
+                    MI3D_TRY(flush_deferred(c, x, grads, accumulate, q == 1 && !mi3d_routes().no_lazy_aux));
+        }
+        if (dfr) {
             if (dx_f) {
                 const bool defer = h == 1 && c.defer_slabs && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
                 int ksd = 0;
@@ -833,7 +868,10 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
     MI3D_TRY(c.flush_pend());
     // weight gradients still queued (a call that ends before the group's own fork point): they go out now, so that every
     // gradient of the segments [seg_begin, seg_end) is at least in flight when the call returns
-    if (c.s2 && c.ev) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+    if (c.s2 && c.ev) {
+        MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+        MI3D_TRY(drain_aux(c, x, grads, accumulate, -1));
+    }
     if (c.aux_used) {
         // event 3 = "the aux stream has finished what this call gave it".  aux_join: the compute stream waits for it here, i.e.
         // everything is ordered before whatever the caller enqueues next on `stream`; otherwise the CALLER orders its consumers

@@ -49,7 +49,17 @@ def _loss_cfg(kind, kd_alpha=None, temperature=2.0):
     return M._cfg(*_LOSS_TABLE[kind])
 
 
-def concurrent_stream(device, candidates=6, hold_us=300):
+def _priority_stream(device, cls):
+    """torch stream object around a hipStream_t of priority class cls (-1 highest, 0 middle, +1 lowest; mi3d_stream_create).
+    The handle lives as long as the process: streams are few and are shared through the per-device cache below."""
+    h = C.c_void_p()
+    call("mi3d_stream_create", int(cls), C.byref(h))
+    st = torch.cuda.ExternalStream(h.value, device=device)
+    st.mi3d_handle = h
+    return st
+
+
+def concurrent_stream(device, candidates=6, hold_us=300, priority="high"):
     """A stream whose kernels really run BESIDE those of the current (compute) stream.  HIP multiplexes streams onto a few
     hardware queues, and two streams that share a queue execute strictly one after the other (measured with rocprofv3: the
     default stream and the 8th stream created in a process both sat on queue 4, and a collective kernel on the latter ran
@@ -61,7 +71,12 @@ def concurrent_stream(device, candidates=6, hold_us=300):
     buf = torch.zeros(1024, dtype=torch.float32, device=device)
     best = None
     for i in range(candidates):
-        c = torch.cuda.Stream(device=device, priority=-1) if i == 0 else torch.cuda.Stream(device=device)
+        if i == 0 and priority == "low":
+            c = _priority_stream(device, +1)
+        elif i == 0 and priority == "high":
+            c = torch.cuda.Stream(device=device, priority=-1)
+        else:
+            c = torch.cuda.Stream(device=device)
         times = []
         for rep in range(2):                       # first pass loads the code object
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -331,7 +346,9 @@ class TrainStep(_StepBase):
         # serial order.  Both forwards are long chains that leave most CUs idle at the deep levels, so they interleave.
         self.kd_stream = concurrent_stream(self.device) if (kd_teacher is not None and overlap_teacher) else None
         # second compute stream: the deferred weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
-        self.aux_stream = concurrent_stream(self.device) if aux_wgrad else None
+        # it has the LOWEST priority class: a free workgroup slot goes to the chain's kernel first (the exchange stream keeps the
+        # highest: a collective must not wait behind either)
+        self.aux_stream = (concurrent_stream(self.device, priority=os.environ.get("MI3D_AUX_PRIO", "high")) if aux_wgrad else None)
         self._events = None
         self._event_handles = []
         if aux_wgrad:

@@ -214,7 +214,7 @@ def _synth(n, s, seed, blocky=True):
     return x, y
 
 
-def test_round2_routes_are_invisible_at_the_headline_shape(routes):
+def test_round2_routes_are_invisible_at_the_headline_shape(routes, golden):
     """96^3, N=2, bf16 -- the kernel routes added in round 2, each switched off in turn against the default build, per TENSOR:
       MI3D_NO_SMALL_BN        BatchNorm statistics finished by a finalize launch instead of the consumer's prologue: the SAME
                               partial rows summed in double in another order -> statistics equal to ~1e-7, everything
@@ -280,8 +280,30 @@ def test_round2_routes_are_invisible_at_the_headline_shape(routes):
         e = relerr(g3[k].cpu(), g0[k].cpu())
         if e > worst:
             worst, wk = e, k
-    print("MI3D_NO_SMALL_BN at 96^3: logits relerr", eo, "worst per-tensor gradient relerr", worst, wk)
-    assert worst < 0.5, (wk, worst)
+    print("MI3D_NO_SMALL_BN at 96^3 (blocky labels): logits relerr", eo, "worst per-tensor gradient relerr", worst, wk)
+    # The bound, tensor by tensor, is the reference's OWN autocast yardstick (as check_summary uses it): on the batch of the
+    # config-2 fixture the two routes may differ by no more than 1.5 x what the reference's bf16-autocast run differs from its
+    # fp32 run on that tensor (floor 5 %) -- both routes are then equally good readings of the reference.
+    g = golden("config2_96")
+    yard = dict(zip(list(g["grad_names"]), g["autocast_bf16/grad_relerr"]))
+    from test_gpu_round2 import synth as synth_cfg2
+    x, y = (t.to(DEV) for t in synth_cfg2(2, 96, 1234))
+    la, oa, ga = run()
+    routes.set("no_small_bn", 1)
+    lb, ob, gb = run()
+    routes.reset("no_small_bn")
+    assert abs(lb - la) < 1e-3 * abs(la)
+    assert relerr(ob.cpu(), oa.cpu()) < 2e-2
+    worst, wk, wtol = 0.0, "", 0.0
+    for k in ga:
+        if float(ga[k].double().norm()) < 1e-7 or noise_only(k):
+            continue
+        e = relerr(gb[k].cpu(), ga[k].cpu())
+        tol = max(0.05, 1.5 * float(yard.get(k, 0.0)))
+        if e / tol > (worst / wtol if wtol else 0.0):
+            worst, wk, wtol = e, k, tol
+        assert e < tol, (k, e, tol)
+    print("MI3D_NO_SMALL_BN on the config-2 batch: worst per-tensor gradient relerr / its yardstick bound", worst, wtol, wk)
 
 
 def test_two_stream_forwards_are_bitwise_the_serial_order():

@@ -908,6 +908,11 @@ def gen_dp2(out):
     d = {}
     for r in range(2):
         for k, v in np.load(os.path.join(tmp, f"r{r}.npz"), allow_pickle=False).items():
+            # DDP all-reduces the gradients: rank 1's slices (and its copies of the name tables) are rank 0's, bit for bit
+            # (asserted here) -- only rank 0's are stored
+            if r == 1 and ("/grad/" in k or k.endswith("/grad_names") or k.endswith("/bn_keys")):
+                assert np.array_equal(v, d["r0/" + k]), k
+                continue
             d[f"r{r}/{k}"] = v
     np.savez_compressed(os.path.join(out, "dp2.npz"), **d)
 
