@@ -276,7 +276,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (BASELINE config 2: 2)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.0, help="run_training.sh:31 ships --dropout_rate 0.0")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="(default since round 4) eager launches")
+    ap.add_argument("--graph", action="store_true", help="one hipGraph per step on one stream (no aux-stream weight gradients)")
     ap.add_argument("--no-aux-wgrad", action="store_true",
                     help="keep every weight gradient on the data-gradient chain (default: the decoder / deep-level ones run on a second stream)")
     ap.add_argument("--chain-prio", default=os.environ.get("MI3D_BENCH_CHAIN_PRIO", "normal"), choices=["normal", "high"],
@@ -327,7 +328,12 @@ def main():
     # one hipGraph per step at world 1.  With gradient exchange (world > 1) the step is launched eagerly: the two exchanges
     # (dp.bucket_ranges) cut the graph into segments, and eager launches measured faster than segmented replay (DESIGN.md §6:
     # 2.447 vs 2.517 ms on the 1-rank RCCL path; eager == full graph without communication); --graph-segments forces the segments
-    use_graph = (not a.no_graph) and ((world == 1 and not a.force_comm) or a.graph_segments)
+    # round 4: the default step launches eagerly with the weight gradients of the decoder / deep levels on an aux stream
+    # (TrainStep aux_wgrad) -- at world 1 and at world > 1 alike, so the single-GPU number and the DP step use one launch mode.
+    # --graph replays ONE hipGraph on one stream instead (the round-3 mode; this runtime's graph executor cannot take the fork)
+    use_graph = a.graph and (not a.no_graph) and ((world == 1 and not a.force_comm) or a.graph_segments)
+    if a.graph_segments and not a.no_graph:
+        use_graph = True
     x, y = synth(a.batch, a.size, 1234 + rank)
     if a.workload == "dann":
         from multimodal_segmentation_project_amd import unet_dann
@@ -347,7 +353,7 @@ def main():
             torch.manual_seed(1)
             teacher = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).eval()
         ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=cdt, kd_teacher=teacher,
-                       use_graph=use_graph, aux_wgrad=not a.no_aux_wgrad, overlap_teacher=not a.serial_forwards)
+                       use_graph=use_graph, aux_wgrad=(False if a.no_aux_wgrad else None), overlap_teacher=not a.serial_forwards)
         ts.load_batch(x.to(dev), y.to(dev))
     if a.workload == "eval":
         xd, yd = x.to(dev), y.to(dev)

@@ -585,6 +585,7 @@ inline bool bn_small(int C, int64_t M) {
 // number of partial rows for a small tensor
 inline int bn_small_rows(int nblk, int C) { return nblk > SMALL_ROWS ? SMALL_ROWS : nblk; }
 bool bn_small_ok(int C, int64_t M, int rows) { return bn_small(C, M) && rows >= 1 && rows <= SMALL_ROWS; }
+bool bn_small_route(int C, int64_t M) { return bn_small(C, M); }
 
 int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* stat,
@@ -676,7 +677,8 @@ int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, flo
 
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta, int accumulate,
-           float* ws, hipStream_t s, const SlabJob* extra, const float* skp, int ks, const SlabJob* extra2) {
+           float* ws, hipStream_t s, const SlabJob* extra, const float* skp, int ks, const SlabJob* extra2, int* reduce_only_rows) {
+    if (reduce_only_rows) *reduce_only_rows = 0;
     MI3D_CHECK_ARG(C >= 1 && C <= BLK && M >= 1, "bn_bwd: bad C=%d", C);
     MI3D_CHECK_ARG(!drop || M < (1ll << 32), "bn_bwd: dropout path needs M < 2^32 (32-bit sample index)");
     float* part = ws;
@@ -701,6 +703,9 @@ int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, i
             bn_bwd_finalize_kernel<<<C, FIN_T, 0, s>>>(part, nblk, C, M, stat, dgamma, dbeta, accumulate, coef);
             MI3D_LAUNCH_CHECK();
         }
+        // apply on load: the consumer (the input-gradient conv) finishes the rows in ITS prologue, computes dy while staging
+        // and writes dgamma / dbeta; nothing more to launch here
+        if (reduce_only_rows && small && v8) { *reduce_only_rows = nblk; return 0; }
         int grid = v8 ? stream_grid(M * (C / 8), C / 8) : stream_grid(M * C, C);
         const T* dzp = (const T*)dz; const T* yp = (const T*)y; T* dyp = (T*)dy;
         if (small && v8) bn_bwd_apply_kernel<T, 8, true><<<grid, BLK, 0, s>>>(dzp, dzcs, yp, ycs, C, M, V, stat, part, nblk, dgamma, dbeta, accumulate, drop, dyp, dycs);

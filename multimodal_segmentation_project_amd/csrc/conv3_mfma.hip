@@ -376,17 +376,34 @@ __global__ __launch_bounds__(BLK) void conv3_mfma_kernel(const bf16* __restrict_
 
 
 // ------------------------------------------------------------------------------------------ eight-wave forward variant
+constexpr size_t conv8_lds(int TY, int TX, int COB) {        // TX == 8 <=> BX == 4 tilings: LDS row pitch 12 voxels (see the kernel)
+    return (size_t)6 * (TY + 2) * (TX == 8 ? 12 : TX + 2) * 32 + (size_t)14 * COB * 1024 + (size_t)8 * COB * 16 * 2 * 4;
+}
+constexpr size_t CONV8_XF_LDS = 256 * 6 * sizeof(float);     // XF coefficient table behind the kernel's own LDS block
 // Levels 1-4 run ONE tile per workgroup with <= 2 workgroups per CU (432 tiles at level 1), so the serial chain of one
 // workgroup (tile loads -> LDS -> K loop -> stores) IS the kernel time.  This variant halves that chain per wave: 8 waves,
 // wave w owns z-slice w & 3 and HALF of the slice's M-blocks (w >> 2); staging is spread over 512 threads; the chunk's weight
 // fragments are staged through LDS once per workgroup (no per-wave register ring, no vector-memory wait inside the K loop),
 // which keeps the kernel under 128 VGPRs = 4 waves per SIMD.  Same arithmetic per output element as conv3_mfma_body (same
 // K order, same fp32 accumulation) -> bit-identical outputs; the statistic partials sum 8 instead of 4 wave rows.
-template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK>
-__global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restrict__ x, int xcs, int Cin,
+//
+// XF != 0 ("apply on load", round 4, small-geometry tiling only): the input tensor is a BatchNorm output that was never
+// written -- the staging pass computes it from the raw tensor(s) between the global load and the LDS store, and the launch
+// that used to do that (bn_apply / bn_bwd_apply: one link of the deep-level chain each) disappears:
+//   XF = 1  forward conv1 of a block:  z1 = relu(a*y0 + b) * drop      (x = y0 of conv0; a, b from conv0's statistics)
+//   XF = 2  input gradient:            dy = g*m*dz + A*y + B            (x = dz, xf.y2 = the layer's own raw output y)
+// The per-channel coefficients come from the <= 128 partial rows the statistics / reduction kernel left (summed in the
+// prologue, in double, like the "small BatchNorm" consumers bn_apply_kernel<TRAIN> / bn_bwd_apply_kernel<SMALL> do); the
+// workgroups of tile 0 / output group 0 publish stat[4][C] + running statistics (XF = 1) or dgamma / dbeta (XF = 2) for the
+// channel chunks they own.  Output group 0 also WRITES the transformed tensor for the voxels inside its tile (xf.side): the
+// weight-gradient kernels of the backward read it (z1 resp. dy) exactly as before.  Element for element the arithmetic is
+// bn_apply_kernel's / bn_bwd_apply_kernel's (same fmaf order, same rounding), so both routes give the same bits.
+template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK, int XF = 0>
+__global__ __launch_bounds__(512, XF == 2 ? 2 : 4) void conv3_mfma8_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                           const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                           bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
-                                                          int tilesZ, int tilesY, int tilesX, float* __restrict__ part, int relu) {
+                                                          int tilesZ, int tilesY, int tilesX, float* __restrict__ part, int relu,
+                                                          XfArgs xf) {
     constexpr int NT = 512;
     constexpr int BY = 16 / BX;
     constexpr int TY = TYB * BY, TX = TXB * BX;
@@ -423,6 +440,7 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
         for (int c = 0; c < COB; c++) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int NIT = (NVOX * 2 + NT - 1) / NT;
     int soff[NIT], sdst[NIT];
+    [[maybe_unused]] int svox[NIT], own = 0;                // XF: voxel index of the piece (second raw tensor, side tensor), "this workgroup writes it" bits
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         int idx = threadIdx.x + it * NT;
@@ -432,6 +450,10 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
         int gz = z0 - 1 + iz, gy = y0 - 1 + iy, gx = x0 - 1 + ix;
         bool inb = idx < NVOX * 2 && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
         soff[it] = inb ? ((gz * H + gy) * W + gx) * xcs + half * 8 : -1;
+        if constexpr (XF != 0) {
+            svox[it] = (gz * H + gy) * W + gx;
+            if (inb && iz >= 1 && iz <= TZ && iy >= 1 && iy <= TY && ix >= 1 && ix <= TX && bid_.y == 0 && xf.side) own |= 1 << it;
+        }
     }
     const bf16* xn = x + (int64_t)n * D * H * W * xcs;
     int nchunk = Cin / 16, chunk0 = 0;
@@ -441,6 +463,15 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
         nchunk = chunk0 + per;
     }
     bf16x8 sv[NIT];
+    [[maybe_unused]] bf16x8 sv2[NIT];
+    [[maybe_unused]] const bf16* x2n = nullptr;
+    [[maybe_unused]] bf16* siden = nullptr;
+    // XF coefficient table [k][256 channels of this workgroup's chunks]: k = a, b, d (Dropout3d scale), and for XF = 2 g, A, B
+    [[maybe_unused]] float* cft = reinterpret_cast<float*>(lds8 + conv8_lds(TY, TX, COB));
+    if constexpr (XF != 0) {
+        x2n = xf.y2 + (int64_t)n * D * H * W * xf.y2cs;
+        siden = xf.side ? xf.side + (int64_t)n * D * H * W * xf.side_cs : nullptr;
+    }
     constexpr int NWI = (14 * COB * 64 + NT - 1) / NT;
     bf16x8 wv[NWI];
     auto load_chunk = [&](int chunk) {
@@ -448,6 +479,10 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
         for (int it = 0; it < NIT; it++) {
             sv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (soff[it] >= 0) sv[it] = *reinterpret_cast<const bf16x8*>(xn + soff[it] + chunk * 16);
+            if constexpr (XF == 2) {
+                sv2[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (soff[it] >= 0) sv2[it] = *reinterpret_cast<const bf16x8*>(x2n + svox[it] * xf.y2cs + (threadIdx.x & 1) * 8 + chunk * 16);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NWI; i++) {
@@ -458,7 +493,65 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
             }
         }
     };
-    load_chunk(chunk0);
+    load_chunk(chunk0);                                   // (XF: in flight under the coefficient prologue)
+    if constexpr (XF != 0) {
+        const int C = xf.C, c0 = chunk0 * 16, nloc = (nchunk - chunk0) * 16;      // channels of the input tensor owned here
+        // sum the partial rows [nrows][2][C] for (k, c) in [0,2) x [c0, c0 + nloc): 512 / (2 nloc) row groups, then the groups
+        // in fixed order.  (Sums of <= 128 fp32 values of one sign pattern in double: the order does not change the result.)
+        double* red8 = reinterpret_cast<double*>(lds8);                               // the tile area is free before the first stage
+        const int npair = 2 * nloc, ngrp = NT / npair;
+        {
+            const int pair = threadIdx.x % npair, grp = threadIdx.x / npair;
+            double acc_ = 0.0;
+            if (grp < ngrp) {
+                const int k = pair / nloc, cc = pair - k * nloc;
+                for (int r = grp; r < xf.nrows; r += ngrp) acc_ += (double)xf.rows[((size_t)r * 2 + k) * C + c0 + cc];
+                red8[grp * npair + pair] = acc_;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nloc) {
+            const int cc = threadIdx.x, c = c0 + cc;
+            double s0 = 0.0, s1 = 0.0;
+            for (int q = 0; q < ngrp; q++) { s0 += red8[q * npair + cc]; s1 += red8[q * npair + nloc + cc]; }
+            const bool pub = xcd_contig(bid_.x, bid_.gx) == 0 && bid_.y == 0;        // tile 0, output group 0: one publisher per chunk range
+            const float dsc = xf.drop ? xf.drop[(size_t)n * C + c] : 1.f;
+            if constexpr (XF == 1) {
+                double mean = s0 / (double)xf.M;
+                double var = s1 / (double)xf.M - mean * mean;
+                if (var < 0.0) var = 0.0;
+                double inv = 1.0 / sqrt(var + (double)xf.eps);
+                float a = (float)((double)xf.gamma[c] * inv);
+                float b = (float)((double)xf.beta[c] - mean * (double)xf.gamma[c] * inv);
+                cft[cc] = a; cft[256 + cc] = b; cft[512 + cc] = dsc;
+                if (pub) {
+                    xf.stat[c] = (float)mean; xf.stat[C + c] = (float)inv; xf.stat[2 * C + c] = a; xf.stat[3 * C + c] = b;
+                    if (xf.momentum < 0.f) {
+                        double* side = reinterpret_cast<double*>(xf.rmean);
+                        if (side) { side[c] = mean; side[C + c] = xf.M > 1 ? var * (double)xf.M / (double)(xf.M - 1) : var; }
+                    } else {
+                        if (xf.rmean) xf.rmean[c] = (float)((1.0 - xf.momentum) * xf.rmean[c] + xf.momentum * mean);
+                        if (xf.rvar) {
+                            double unb = xf.M > 1 ? var * (double)xf.M / (double)(xf.M - 1) : var;
+                            xf.rvar[c] = (float)((1.0 - xf.momentum) * xf.rvar[c] + xf.momentum * unb);
+                        }
+                        if (xf.nbt && c == 0) *xf.nbt += 1;
+                    }
+                }
+            } else {
+                const float mean = xf.stat[c], inv = xf.stat[C + c], a = xf.stat[2 * C + c], b = xf.stat[3 * C + c];
+                const float cf0 = (float)(s0 / (double)xf.M), cf1 = (float)(s1 / (double)xf.M);
+                const float gg = a, k = gg * cf1 * inv;
+                cft[cc] = a; cft[256 + cc] = b; cft[512 + cc] = dsc;
+                cft[768 + cc] = gg; cft[1024 + cc] = -k; cft[1280 + cc] = k * mean - gg * cf0;
+                if (pub) {
+                    if (xf.dgamma) xf.dgamma[c] = xf.accumulate ? xf.dgamma[c] + (float)s1 : (float)s1;
+                    if (xf.dbeta) xf.dbeta[c] = xf.accumulate ? xf.dbeta[c] + (float)s0 : (float)s0;
+                }
+            }
+        }
+        // (the first chunk's barrier in front of the LDS stores orders the table writes before their first use)
+    }
     auto frag_off = [&](int s) {
         int t0 = 2 * s, t1 = (2 * s + 1 < 27) ? 2 * s + 1 : 26;
         int off0 = (((t0 / 9) * IY + ((t0 / 3) % 3)) * IXP + (t0 % 3)) * 32;
@@ -468,6 +561,44 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
     auto row_off = [&](int r) { int rg = hb * MBW + r; return (((rg / TXB) * BY) * IXP + (rg % TXB) * BX) * 32; };
     for (int chunk = chunk0; chunk < nchunk; chunk++) {
         __syncthreads();
+        if constexpr (XF != 0) {
+            // this thread's 8 channels of the chunk: (chunk - chunk0) * 16 + (threadIdx.x & 1) * 8 (NT is even: `half` is fixed);
+            // four channels at a time, so that the coefficient registers stay few (the kernel lives under 128 VGPRs)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float* ct = cft + (chunk - chunk0) * 16 + (threadIdx.x & 1) * 8 + q * 4;
+                const f32x4 ca = *reinterpret_cast<const f32x4*>(ct), cb = *reinterpret_cast<const f32x4*>(ct + 256),
+                            cd = *reinterpret_cast<const f32x4*>(ct + 512);
+                [[maybe_unused]] f32x4 cg, cA, cB;
+                if constexpr (XF == 2) {
+                    cg = *reinterpret_cast<const f32x4*>(ct + 768); cA = *reinterpret_cast<const f32x4*>(ct + 1024);
+                    cB = *reinterpret_cast<const f32x4*>(ct + 1280);
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    if (soff[it] < 0) continue;                  // outside the volume: the conv's zero padding, not a transformed zero
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if constexpr (XF == 1) {
+                            float t = fmaf((float)sv[it][q * 4 + i], ca[i], cb[i]);
+                            t = t > 0.f ? t : 0.f;
+                            sv[it][q * 4 + i] = (bf16)(t * cd[i]);
+                        } else {
+                            const float yv = (float)sv2[it][q * 4 + i], gv = (float)sv[it][q * 4 + i];
+                            const float pre = fmaf(yv, ca[i], cb[i]);
+                            const float m = pre > 0.f ? cd[i] : 0.f;
+                            sv[it][q * 4 + i] = (bf16)fmaf(cg[i] * m, gv, fmaf(cA[i], yv, cB[i]));
+                        }
+                    }
+                }
+            }
+            if (own) {
+#pragma unroll
+                for (int it = 0; it < NIT; it++)
+                    if (own & (1 << it))
+                        *reinterpret_cast<bf16x8*>(siden + svox[it] * xf.side_cs + (threadIdx.x & 1) * 8 + chunk * 16) = sv[it];
+            }
+        }
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             int idx = threadIdx.x + it * NT;
@@ -480,11 +611,11 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
         }
         __syncthreads();
         if (chunk + 1 < nchunk) load_chunk(chunk + 1);        // in flight under this chunk's K loop
-        bf16x8 xf[2][MBW];
+        bf16x8 xq[2][MBW];
         {
             int toff = frag_off(0);
 #pragma unroll
-            for (int r = 0; r < MBW; r++) xf[0][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(r));
+            for (int r = 0; r < MBW; r++) xq[0][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(r));
         }
 #pragma unroll
         for (int s = 0; s < 14; s++) {
@@ -494,12 +625,12 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
             if (s + 1 < 14) {
                 int toff = frag_off(s + 1);
 #pragma unroll
-                for (int r = 0; r < MBW; r++) xf[(s + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(r));
+                for (int r = 0; r < MBW; r++) xq[(s + 1) & 1][r] = *reinterpret_cast<const bf16x8*>(xsb + toff + row_off(r));
             }
 #pragma unroll
             for (int r = 0; r < MBW; r++)
 #pragma unroll
-                for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wcur[c], xf[s & 1][r], acc[r][c]);
+                for (int c = 0; c < COB; c++) acc[r][c] = mfma16(wcur[c], xq[s & 1][r], acc[r][c]);
         }
     }
     if constexpr (SPLITK) {
@@ -563,9 +694,6 @@ __global__ __launch_bounds__(512, 4) void conv3_mfma8_kernel(const bf16* __restr
             part[((int64_t)bid_.x * 2 + k) * CoutTotal + cobBase * 16 + ch] = v;
         }
     }
-}
-constexpr size_t conv8_lds(int TY, int TX, int COB) {        // TX == 8 <=> BX == 4 tilings: LDS row pitch 12 voxels (see the kernel)
-    return (size_t)6 * (TY + 2) * (TX == 8 ? 12 : TX + 2) * 32 + (size_t)14 * COB * 1024 + (size_t)8 * COB * 16 * 2 * 4;
 }
 
 // ------------------------------------------------------------------------------------------ persistent variant
@@ -1141,7 +1269,8 @@ __global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restr
 
 template <int TZ, int TYB, int TXB, int BX, int COB>
 int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bias, bf16* y, int ycs, int Cout, Geo g,
-               float* part, int ksplit, float* skws, hipStream_t s, bool defer_finish = false, int relu = 0) {
+               float* part, int ksplit, float* skws, hipStream_t s, bool defer_finish = false, int relu = 0,
+               const XfArgs* xf = nullptr) {
     constexpr int TY = TYB * (16 / BX), TX = TXB * BX;
     int tz = cdiv(g.D, TZ), ty = cdiv(g.H, TY), tx = cdiv(g.W, TX);
     dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)), (unsigned)ksplit);
@@ -1149,11 +1278,29 @@ int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bia
     static_assert((TYB * TXB) % 2 == 0, "tile shapes used here have an even number of M-blocks per slice");
     const bool w8 = mi3d_routes().conv8 != 0;
     constexpr size_t lds8 = conv8_lds(TY, TX, COB);
+#define LC8X(ST_, SK_, XF_, PART_, BIAS_, RELU_)                                                                               \
+    do {                                                                                                                       \
+        MI3D_SET_MAX_LDS_ONCE((&conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, ST_, SK_, XF_>), lds8 + CONV8_XF_LDS);               \
+        conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, ST_, SK_, XF_><<<grid, 512, lds8 + (XF_ ? CONV8_XF_LDS : 0), s>>>(x, xcs, Cin, wp, BIAS_, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, PART_, RELU_, xf ? *xf : XfArgs()); \
+    } while (0)
+    // apply on load: only the small-geometry tiling with two output blocks carries the transform (TX == 8, COB == 2)
+    constexpr bool XF_CFG = TX == 8 && COB == 2;
+    const int xfm = xf ? xf->mode : 0;
+    MI3D_CHECK_ARG(xfm == 0 || (XF_CFG && w8 && xf->C == Cin && Cin <= 256 && xf->rows && xf->nrows > 0 && xf->stat &&
+                                (xfm == 1 || (xfm == 2 && xf->y2))),
+                   "conv3_mfma: this launch cannot apply BatchNorm on load");
+#ifdef MI3D_EXPERIMENTS      // the apply-on-load kernels are a measured-slower experiment: experiment builds only
 #define LC8(ST_, SK_, PART_, BIAS_, RELU_)                                                                                     \
     do {                                                                                                                       \
-        MI3D_SET_MAX_LDS_ONCE((&conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, ST_, SK_>), lds8);                                   \
-        conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, ST_, SK_><<<grid, 512, lds8, s>>>(x, xcs, Cin, wp, BIAS_, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, PART_, RELU_); \
+        if constexpr (XF_CFG) {                                                                                                \
+            if (xfm == 1) { LC8X(ST_, SK_, 1, PART_, BIAS_, RELU_); break; }                                                    \
+            if (xfm == 2) { LC8X(ST_, SK_, 2, PART_, BIAS_, RELU_); break; }                                                    \
+        }                                                                                                                      \
+        LC8X(ST_, SK_, 0, PART_, BIAS_, RELU_);                                                                                \
     } while (0)
+#else
+#define LC8(ST_, SK_, PART_, BIAS_, RELU_) LC8X(ST_, SK_, 0, PART_, BIAS_, RELU_)
+#endif
     if (ksplit > 1) {
         if (w8) LC8(false, true, skws, nullptr, 0);
         else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, true><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, nullptr, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, skws, 0);
@@ -1169,6 +1316,7 @@ int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bia
         else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr, relu);
     }
 #undef LC8
+#undef LC8X
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -1256,9 +1404,18 @@ int conv3_bwd_ks_target() {
     return kst < 1 ? 1 : kst;
 }
 
+bool conv3_mfma_xform_ok(int Cin, int Cout, Geo g) {
+#ifndef MI3D_EXPERIMENTS
+    return false;
+#endif
+    return !big_geo(g) && !persist_ok(Cin, Cout, g) && Cout % 32 == 0 && Cin % 16 == 0 && Cin <= 256 && mi3d_routes().conv8 != 0;
+}
+
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
-                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred, int relu, int ks_target) {
+                   float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred, int relu, int ks_target,
+                   const XfArgs* xf) {
     if (ks_deferred) *ks_deferred = 0;
+    MI3D_CHECK_ARG(!xf || xf->mode == 0 || conv3_mfma_xform_ok(Cin, Cout, g), "conv3_mfma_fwd: no apply-on-load kernel for %d->%d here", Cin, Cout);
     MI3D_CHECK_ARG((!xh.on() && !yh.on()) || persist_ok(Cin, Cout, g), "conv3_mfma_fwd: planar halves need the persistent kernel");
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, ycs), "conv3_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
     MI3D_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, "conv3_mfma_fwd: misaligned tensors");
@@ -1312,7 +1469,7 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     }
     bool defer = ks > 1 && ks_deferred;
     if (defer) *ks_deferred = ks;
-    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer, relu);
+    if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer, relu, xf);
     return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, ks, skws, s, defer, relu);
 }
 

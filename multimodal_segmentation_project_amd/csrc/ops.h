@@ -50,9 +50,29 @@ bool conv3_mfma_fuses_stats(int Cin, int Cout, Geo g);        // false -> caller
 // Default = ordinary single-plane tensor.  Only the persistent full-resolution kernels and wgrad honour it.
 struct Halves { int split = 1 << 30; int64_t delta = 0; bool on() const { return delta != 0; } };
 bool conv3_mfma_halves_ok(int Cin, int Cout, Geo g);          // forward (Cin,Cout) launch can take Halves x / y
+// "Apply on load" (round 4; deep levels, conv3_mfma8_kernel): the conv's input tensor is a BatchNorm output that is computed in
+// the staging pass from the raw tensor(s) instead of being written by its own launch.  mode 1: x = raw conv output y0 of the
+// layer in front, input = relu(a*x + b) * drop (forward conv1 of a block); mode 2: x = dz, y2 = the layer's raw output,
+// input = BatchNorm/ReLU/Dropout3d backward of dz (the input-gradient conv).  rows = the <= 128 partial rows
+// [nrows][2][C] the statistics (mode 1) / reduction (mode 2) kernel left; side = where the transformed tensor is written
+// as a by-product (z1 resp. dy, for the weight-gradient kernels), NULL = nowhere.
+struct XfArgs {
+    int mode = 0;
+    const bf16* y2 = nullptr; int y2cs = 0;
+    float* stat = nullptr;                       // [4][C]: written (mode 1) / read (mode 2)
+    const float* rows = nullptr; int nrows = 0;
+    int64_t M = 0;                               // elements per channel
+    int C = 0;                                   // channels of the transformed tensor (= Cin of the conv)
+    const float* gamma = nullptr; const float* beta = nullptr; float* rmean = nullptr; float* rvar = nullptr; int64_t* nbt = nullptr;
+    float momentum = 0.f, eps = 0.f;
+    float* dgamma = nullptr; float* dbeta = nullptr; int accumulate = 0;
+    const float* drop = nullptr;                 // [N][C] Dropout3d scales or NULL
+    bf16* side = nullptr; int side_cs = 0;
+};
+bool conv3_mfma_xform_ok(int Cin, int Cout, Geo g);           // the launch conv3_mfma_fwd(Cin, Cout, g) would make can take XfArgs
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
                    Geo g, float* part, float* skws, hipStream_t s, Halves xh = Halves(), Halves yh = Halves(),
-                   int* ks_deferred = nullptr, int relu = 0, int ks_target = 0);
+                   int* ks_deferred = nullptr, int relu = 0, int ks_target = 0, const XfArgs* xf = nullptr);
 // ks_target > 0: split-K workgroup target of this launch (0 = the forward default).  The input-gradient convs of the backward
 // use conv3_bwd_ks_target() in the fused launch AND when they run stand-alone, so both routes produce the same bits
 int conv3_bwd_ks_target();
@@ -140,7 +160,10 @@ int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, flo
 int bn_bwd(int dtype, const void* dz, int dzcs, const void* y, int ycs, int C, int64_t M, int64_t V,
            const float* stat, const float* drop, void* dy, int dycs, float* dgamma, float* dbeta,
            int accumulate, float* ws, hipStream_t s, const SlabJob* extra = nullptr, const float* skp = nullptr, int ks = 0,
-           const SlabJob* extra2 = nullptr);
+           const SlabJob* extra2 = nullptr, int* reduce_only_rows = nullptr);
+// reduce_only_rows != NULL and the tensor takes the "small" route: only the reduction is launched; *reduce_only_rows = the number
+// of partial rows it leaves in ws ([rows][2][C]) for a consumer that applies on load (XfArgs mode 2), else 0 and nothing changes
+bool bn_small_route(int C, int64_t M);       // the statistics / reduction of a (C, M) tensor leave <= 128 rows for the consumer's prologue
 // skp != NULL: dz is still the ks fp32 split-K partials [ks][M][C] of the conv that produced it; the reduction sums and
 // rounds them and WRITES dz (the split-K finishing launch of that conv is skipped by the caller)
 // extra: a pending slab sum that rides in the reduction kernel's launch (extra blocks)

@@ -287,10 +287,12 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
     block_input(c, b, x, xin, xcs, xdt);
     void* zout; int zcs;
     block_output(c, b, zout, zcs);
+    XfArgs xfa;                      // conv0's BatchNorm + ReLU + Dropout3d applied in conv1's staging pass (deep levels)
     for (int h = 0; h < 2; h++) {
         const HalfP& H = B.h[h];
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
+        if (h == 1 && xfa.mode) { in = c.at(B.h[0].y); ics = B.h[0].Cout; }     // the raw conv0 output; z1 is written as a by-product
         float* rm = buffers ? (float*)buffers[H.bidx] : nullptr;
         float* rv = buffers ? (float*)buffers[H.bidx + 1] : nullptr;
         int64_t* nbt = buffers ? (int64_t*)buffers[H.bidx + 2] : nullptr;
@@ -308,7 +310,8 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             // round 2: the 8-16-chunk K loops on 32-216 workgroups cost more than the launch they save; that route is gone.)
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
                                     training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
-                                    (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr));
+                                    (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr, 0, 0,
+                                    (h == 1 && xfa.mode) ? &xfa : nullptr));
             fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
         } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !mi3d_routes().force_direct &&
                    !mi3d_routes().no_c1_mfma) {
@@ -337,6 +340,17 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
         BnSmall sm{c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps};
+        if (h == 0 && training && small_rows > 0 && p.dt == MI3D_BF16 && B.h[1].mfma && mi3d_routes().apply_on_load &&
+            conv3_mfma_xform_ok(B.h[1].Cin, B.h[1].Cout, g)) {
+            // no apply launch: conv1 finishes the statistics rows in its prologue, applies while staging and writes z1 on the way
+            xfa.mode = 1;
+            xfa.stat = c.at<float>(H.stat); xfa.rows = c.at<float>(p.bnws); xfa.nrows = small_rows; xfa.M = g.M(); xfa.C = H.Cout;
+            xfa.gamma = c.P(H.pidx + 2); xfa.beta = c.P(H.pidx + 3); xfa.rmean = rm; xfa.rvar = rv; xfa.nbt = nbt;
+            xfa.momentum = mom; xfa.eps = p.d.bn_eps;
+            xfa.drop = (drop && training) ? drop + H.drop_off : nullptr;
+            xfa.side = (bf16*)zo; xfa.side_cs = zocs;
+            continue;
+        }
         if (h == 1 && pooled)
             MI3D_TRY(bn_apply_relu_drop_pool(p.dt, c.at(H.y), H.Cout, H.Cout, g, c.at<float>(H.stat),
                                              (drop && training) ? drop + H.drop_off : nullptr, zo, zocs, pooled, pcs, c.s,
@@ -413,16 +427,21 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         void* dyb = dfr ? c.at(H.dyk) : c.at((k & 1) ? p.sB2 : p.sB);
         const void* dz = h == 1 ? dz2 : c.at(p.sC);
         int dcs = h == 1 ? dzcs : H.Cout;
-        MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
-                        drop ? drop + H.drop_off : nullptr, dyb, H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
-                        c.at<float>(p.bnws), c.s, c.has_pend ? &c.pend : (c.has_pend2 ? &c.pend2 : nullptr), h == 0 ? dz_skp : nullptr,
-                        h == 0 ? dz_ks : 0, (c.has_pend && c.has_pend2) ? &c.pend2 : nullptr));
-        c.has_pend = false;
-        c.has_pend2 = false;
         const void* in = h == 0 ? xin : c.at(B.z1);
         int ics = h == 0 ? xcs : H.Cout, idt = h == 0 ? xdt : p.dt;
         void* dx_f = h == 1 ? c.at(p.sC) : dxin;
         int dxs_f = h == 1 ? H.Cin : dxcs;
+        // apply on load (deep levels, deferred layers): only the reduction is launched; the input-gradient conv computes dy while
+        // staging (dz, y), writes it to the layer's dy buffer for the weight gradient, and publishes dgamma / dbeta
+        int xf_rows = 0;
+        const bool want_xf = dfr && dx_f && p.dt == MI3D_BF16 && mi3d_routes().apply_on_load && dcs % 8 == 0 &&
+                             conv3_mfma_xform_ok(H.Cout, H.Cin, g) && bn_small_route(H.Cout, g.M());
+        MI3D_TRY(bn_bwd(p.dt, dz, dcs, c.at(H.y), H.Cout, H.Cout, g.M(), g.V(), c.at<float>(H.stat),
+                        drop ? drop + H.drop_off : nullptr, dyb, H.Cout, G(H.pidx + 2), G(H.pidx + 3), accumulate,
+                        c.at<float>(p.bnws), c.s, c.has_pend ? &c.pend : (c.has_pend2 ? &c.pend2 : nullptr), h == 0 ? dz_skp : nullptr,
+                        h == 0 ? dz_ks : 0, (c.has_pend && c.has_pend2) ? &c.pend2 : nullptr, want_xf ? &xf_rows : nullptr));
+        c.has_pend = false;
+        c.has_pend2 = false;
         if (dfr) {
             // the chain runs the input-gradient conv alone; the weight gradient is queued for the aux stream.  Its slab partition
             // is the fused launch's (conv3_mfma_bwd_wg_target), the input gradient uses the fused launch's split-K factor and the
@@ -430,25 +449,40 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             const int awt = mi3d_routes().aux_wg_target;
             c.dq[c.ndq++] = Ctx::DJob{b, h, awt > 0 ? awt : conv3_mfma_bwd_wg_target(H.Cin, H.Cout, ics, H.Cout, dx_f ? dxs_f : 8, g)};
         }
-        // fork points: what is queued goes to the aux stream when the chain has finished the BatchNorm backward of the last layer
-        // of a group (whether or not that very layer is deferred under the current defer_mask)
-        if (aux) {
+        // fork points: what is queued goes to the aux stream when the chain has finished the last layer of a group -- its
+        // BatchNorm backward, or (apply on load) the input-gradient conv that writes dy -- whether or not that very layer is
+        // deferred under the current defer_mask
+        auto fork_here = [&]() -> int {
+            if (!aux) return 0;
             if (mi3d_routes().defer_fork_each) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
             // group 1 forks when the GPU is still busy with the full-resolution decoder (the host is far ahead: enqueue at once);
             // group 2 forks at the end of the launch-bound deep chain: its launches are fed in between the chain's next ones
             for (int q = 0; q < 2; q++)
                 if (b == p.flush_b[q] && h == p.flush_h[q])
                     MI3D_TRY(flush_deferred(c, x, grads, accumulate, q == 1 && !mi3d_routes().no_lazy_aux));
-        }
+            return 0;
+        };
+        if (xf_rows == 0) MI3D_TRY(fork_here());
         if (dfr) {
             if (dx_f) {
                 const bool defer = h == 1 && c.defer_slabs && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
                 int ksd = 0;
-                MI3D_TRY(conv3_mfma_fwd(dyb, H.Cout, H.Cout, c.at(H.wpd), nullptr, dx_f, dxs_f, H.Cin, g, nullptr,
+                XfArgs xb;
+                if (xf_rows > 0) {
+                    xb.mode = 2;
+                    xb.y2 = (const bf16*)c.at(H.y); xb.y2cs = H.Cout;
+                    xb.stat = c.at<float>(H.stat); xb.rows = c.at<float>(p.bnws); xb.nrows = xf_rows; xb.M = g.M(); xb.C = H.Cout;
+                    xb.dgamma = G(H.pidx + 2); xb.dbeta = G(H.pidx + 3); xb.accumulate = accumulate;
+                    xb.drop = drop ? drop + H.drop_off : nullptr;
+                    xb.side = (bf16*)dyb; xb.side_cs = H.Cout;
+                }
+                MI3D_TRY(conv3_mfma_fwd(xf_rows > 0 ? dz : dyb, xf_rows > 0 ? dcs : H.Cout, H.Cout, c.at(H.wpd), nullptr, dx_f, dxs_f, H.Cin, g, nullptr,
                                         (dxs_f % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s, Halves(),
-                                        (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), defer ? &ksd : nullptr, 0, conv3_bwd_ks_target()));
+                                        (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), defer ? &ksd : nullptr, 0, conv3_bwd_ks_target(),
+                                        xf_rows > 0 ? &xb : nullptr));
                 if (ksd > 0) { dz_skp = c.at<float>(p.skws); dz_ks = ksd; }
             }
+            if (xf_rows > 0) MI3D_TRY(fork_here());        // dy exists only now
             continue;
         }
         if (H.mfma && dx_f && (G(H.pidx) || G(H.pidx + 1)) && conv3_mfma_bwd_fused_persist_ok(H.Cin, H.Cout, ics, H.Cout, g)) {

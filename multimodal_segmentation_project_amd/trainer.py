@@ -316,11 +316,13 @@ class _StepBase:
 class TrainStep(_StepBase):
     def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
                  grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
-                 compute_dtype=None, use_graph=False, aux_wgrad=True, reference_zero_grad_quirk=False,
+                 compute_dtype=None, use_graph=False, aux_wgrad=None, reference_zero_grad_quirk=False,
                  force_comm=False, overlap_teacher=True, keep_logits=False):
         """aux_wgrad: the backward's critical path is the input-gradient chain alone -- the weight gradients of the decoder's
         full-resolution convs and of all deep-level convs run on a second stream (include/mi3d.h, mi3d_unet_backward: aux_stream),
-        forked from the chain at most three times and joined in front of the optimizer; bit-identical results.
+        forked from the chain at most three times and joined in front of the optimizer; bit-identical results.  None (default):
+        on for eager launches, off under use_graph -- this runtime's hipGraph executor spreads a forked graph over three hardware
+        queues and replays it at half speed (4.4 vs 2.2 ms, profiles/r04_defer_graph_streams.txt), eager launches do not.
         keep_logits: the step folds the 1x1x1 head into the loss and never writes the logits (mi3d_unet_forward_loss); True
         keeps a copy in the static buffer `logits` for callers that read them after step().
         reference_zero_grad_quirk: train_unet.py:222 / finetune_ct.py:161 call optimizer.zero_grad() INSIDE
@@ -346,8 +348,9 @@ class TrainStep(_StepBase):
         # serial order.  Both forwards are long chains that leave most CUs idle at the deep levels, so they interleave.
         self.kd_stream = concurrent_stream(self.device) if (kd_teacher is not None and overlap_teacher) else None
         # second compute stream: the deferred weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
-        # it has the LOWEST priority class: a free workgroup slot goes to the chain's kernel first (the exchange stream keeps the
-        # highest: a collective must not wait behind either)
+        # (priority classes measured at 96^3, eager: high 2.111 / normal 2.121 / low 2.124 ms -- profiles/r04_experiments_aux_wgrad.txt)
+        if aux_wgrad is None:
+            aux_wgrad = not use_graph
         self.aux_stream = (concurrent_stream(self.device, priority=os.environ.get("MI3D_AUX_PRIO", "high")) if aux_wgrad else None)
         self._events = None
         self._event_handles = []

@@ -31,7 +31,7 @@ def test_trainstep_bench_path_vs_config2_96_reference_fixture(golden, dtype, gra
     fp32 = dtype == torch.float32
     m = default_model().to(DEV).train()
     ts = TrainStep(m, loss="combined", lr=0.0, weight_decay=0.01, compute_dtype=dtype, use_graph=graph, keep_logits=False)
-    assert ts.aux_stream is not None
+    assert (ts.aux_stream is not None) == (not graph)        # default: aux-stream weight gradients for eager launches only
     x, y = synth(2, 96, 1234)
     ts.load_batch(x.to(DEV), y.to(DEV))
     out = ts.step_static().cpu()
@@ -77,3 +77,61 @@ def test_deferred_weight_gradients_are_bitwise_the_chain_route(size, graph):
     assert torch.equal(p0, p1)
     for a, b in zip(b0, b1):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("size,graph,aux", [(96, False, True), (96, True, False), (32, False, True), (48, False, True), (64, True, False)])
+def test_apply_on_load_is_bitwise_the_launched_apply(routes, size, graph, aux):
+    """Deep levels: conv0's BatchNorm + ReLU + Dropout3d is applied in conv1's staging pass (forward; z1 written as a by-product),
+    and a deferred layer's BatchNorm backward in the staging pass of its input-gradient conv (dy written as a by-product for the
+    weight gradient on the aux stream) -- models/unet.py:12-18 fixes WHAT is computed, not in which launch.  Against the route
+    with the bn_apply / bn_bwd_apply launches (the default; apply_on_load = 0): metrics, every gradient, parameters after AdamW, BatchNorm
+    buffers incl. num_batches_tracked, bit for bit; with Dropout3d masks (per-sample scales enter the staging coefficients)."""
+    if not _lib.lib().mi3d_debug_experiments():
+        pytest.skip("apply on load is compiled into experiment builds only (make EXPERIMENTS=1): measured slower, off the product path")
+    x, y = synth(2, size, 777, blocky=True)
+    res = []
+    for on in (1, 0):
+        routes.set("apply_on_load", on)
+        m = default_model().to(DEV).train()
+        ts = TrainStep(m, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=graph, aux_wgrad=aux)
+        ts.load_batch(x.to(DEV), y.to(DEV))
+        outs = [ts.step_static().clone() for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((outs, ts.arena.g.clone(), ts.arena.p.clone(), [b.clone() for b in m.buffers()]))
+        spans = [(k, o, p.numel()) for (k, p), o in zip(m.named_parameters(), ts.arena.offsets)]
+        ts.close()
+    routes.reset("apply_on_load")
+    (o0, g0, p0, b0), (o1, g1, p1, b1) = res
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b), (a, b)
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    if not torch.equal(g0, g1):
+        bad = [(k, relerr(g0[o:o + n].cpu(), g1[o:o + n].cpu())) for k, o, n in spans if not torch.equal(g0[o:o + n], g1[o:o + n])]
+        raise AssertionError(f"{len(bad)} gradient tensors differ between the routes: {bad[:8]}")
+    assert torch.equal(p0, p1)
+    for (k, _), a, b in zip(m.named_buffers(), b0, b1):
+        assert torch.equal(a, b), k
+
+
+def test_apply_on_load_with_dropout_masks(routes):
+    """The same comparison with Dropout3d(p = 0.3) in train mode: the injected per-(sample, channel) scales must reach the staging
+    coefficients of the right sample (tile -> sample) in both directions."""
+    if not _lib.lib().mi3d_debug_experiments():
+        pytest.skip("apply on load is compiled into experiment builds only (make EXPERIMENTS=1)")
+    x, y = synth(2, 32, 778, blocky=True)
+    res = []
+    for on in (1, 0):
+        routes.set("apply_on_load", on)
+        torch.manual_seed(0)            # also the seed of the model's counter-based dropout stream: the same masks on both routes
+        m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.3).to(DEV).train()
+        ts = TrainStep(m, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=False, aux_wgrad=True)
+        ts.load_batch(x.to(DEV), y.to(DEV))
+        outs = [ts.step_static().clone() for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((outs, ts.arena.g.clone(), ts.arena.p.clone()))
+        ts.close()
+    routes.reset("apply_on_load")
+    (o0, g0, p0), (o1, g1, p1) = res
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b), (a, b)
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)
