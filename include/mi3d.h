@@ -48,6 +48,11 @@ typedef struct mi3d_unet_desc {
     int32_t N, D, H, W;                     /* per-GPU batch and volume; D,H,W divisible by 2^n_levels */
     int32_t dtype;                          /* internal activation dtype */
     float bn_momentum, bn_eps;              /* 0.1, 1e-5 (nn.BatchNorm3d defaults) */
+    int32_t prepacked_from;                 /* 0 (default): a training forward packs every MFMA weight image itself.  k > 0: the images
+                                             * of the DoubleConv blocks with index >= k (order: encoder.0..L-1, bottleneck, decoder.0..L-1)
+                                             * and of all transposed convs in `workspace` are current -- the caller ran
+                                             * mi3d_unet_pack_from(first_block = k) on the same workspace after its last parameter
+                                             * update -- and the forward packs only blocks < k.  Read by mi3d_unet_forward* only. */
 } mi3d_unet_desc;
 
 /* Parameter / buffer pointer tables follow nn.Module.parameters() / .buffers() order of the reference model:
@@ -108,6 +113,18 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
  * `stream` wait for it before the call returns (the call is then stream-ordered for the caller), aux_join == 0 leaves that
  * to the caller: whatever consumes the gradients (optimizer, gradient exchange) and the end of a hipGraph capture must wait
  * for events[3] / aux_stream.  Results are bit-identical to the single-stream route. */
+/* Optimizer tail beside the end of the backward (round 4).  With an aux stream the weight gradients of the leading encoder
+ * blocks (the full-resolution levels) are the LAST thing the compute stream produces, everything else is complete on the aux
+ * stream earlier: the caller can run the optimizer update of the other parameters and re-pack their MFMA weight images THERE,
+ * and only the update of the leading blocks behind the join (train_unet.py:226 fixes no order between parameters).
+ *   mi3d_unet_chain_tail_blocks: k = number of leading encoder blocks whose gradients come last (0: do not split).  Valid
+ *     when mi3d_unet_backward*(seg 0 .. all, aux_stream, aux_join = 0) has returned: aux_stream is then ordered after every
+ *     gradient of the blocks >= k, of the transposed convs and of the head (routes as they are NOW: ask before every step).
+ *   mi3d_unet_pack_from: the weight packs of blocks >= first_block and of all transposed convs, one launch on `stream`
+ *     (what the forward does for all blocks when desc.prepacked_from == 0). */
+int mi3d_unet_chain_tail_blocks(const mi3d_unet_desc* d);
+int mi3d_unet_pack_from(const mi3d_unet_desc* d, const void* const* params, void* workspace, size_t workspace_bytes,
+                        int first_block, void* stream);
 int mi3d_event_create(void** event_out);
 int mi3d_event_destroy(void* event);
 /* A non-blocking hipStream_t of a priority class: -1 = the device's highest, 0 = middle, +1 = lowest.  torch.cuda.Stream only

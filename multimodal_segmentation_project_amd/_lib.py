@@ -20,7 +20,8 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 class UNetDesc(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("n_levels", C.c_int32),
                 ("features", C.c_int32 * MAX_LEVELS), ("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32),
-                ("W", C.c_int32), ("dtype", C.c_int32), ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
+                ("W", C.c_int32), ("dtype", C.c_int32), ("bn_momentum", C.c_float), ("bn_eps", C.c_float),
+                ("prepacked_from", C.c_int32)]
 
 
 class LossCfg(C.Structure):
@@ -55,6 +56,8 @@ _SIGS = {
     "mi3d_unet_infer": (i32, [_DP, vp, vp, vp, vp, vp, vp, sz, vp]),
     "mi3d_unet_bn_apply_deferred": (i32, [_DP, vp, vp, vp]),
     "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp, i32]),
+    "mi3d_unet_chain_tail_blocks": (i32, [_DP]),
+    "mi3d_unet_pack_from": (i32, [_DP, C.POINTER(vp), vp, sz, i32, vp]),
     "mi3d_event_create": (i32, [C.POINTER(vp)]),
     "mi3d_event_destroy": (i32, [vp]),
     "mi3d_stream_create": (i32, [i32, C.POINTER(vp)]),

@@ -71,6 +71,9 @@ void mi3d_set_error(const char* fmt, ...);
     X(defer_mask, 7)        /* which weight gradients go to the aux stream: 1 decoder level 0, 2 decoder level 1, 4 deep levels */ \
     X(aux_wg_target, 0)     /* workgroups of a weight gradient on the aux stream (0: the fused launch's partition) */ \
     X(apply_on_load, 0)     /* MI3D_EXPERIMENTS builds only (round 4, measured slower): deep levels apply BatchNorm in the next conv's staging pass instead of a bn_apply / bn_bwd_apply launch */ \
+    X(no_pool_splitk, 0)    /* 1: a split-K gradient of a pooled tensor is finished by its own pass, not inside the MaxPool3d backward */ \
+    X(g1_fork_late, 0)      /* 1: the decoder's full-resolution weight gradients fork when the chain enters the deep levels */ \
+    X(opt_tail, 0)          /* 1: AdamW + weight re-pack of everything but the leading encoder blocks on the aux stream beside the end of the backward (TrainStep reads it; measured neutral: the aux stream is the long pole there) */ \
     X(no_lazy_aux, 0)       /* 1: the deep-level weight gradients are enqueued on the aux stream all at once at their fork */ \
     X(aux_drain, 3)         /* forked weight gradients the host enqueues on the aux stream per conv layer of the chain */ \
     X(defer_fork_each, 0)   /* 1: every deferred weight gradient goes to the aux stream as soon as its dy exists (one event record per layer; the chain still never waits) */ \

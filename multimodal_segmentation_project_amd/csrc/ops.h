@@ -179,7 +179,8 @@ int bn_train_stats_splitk(const float* skp, int ks, const float* bias, void* y, 
 int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int pcs, hipStream_t s);
 // dz = dskip (or 0) + route(dp) to the first max in (d,h,w) scan order
 int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs,
-                 void* dz, int dzcs, int C, Geo g, hipStream_t s);
+                 void* dz, int dzcs, int C, Geo g, hipStream_t s, const float* skp = nullptr, int ks = 0);
+// skp / ks: dp has not been written -- it is still the ks fp32 split-K partials [ks][M/8][C] of the conv that produces it
 
 // F.interpolate(x, size=...) nearest, models/unet.py:81-83 (volume sides not divisible by 2^levels).  gi = input
 // geometry, go = output geometry; backward is the gather-form adjoint (deterministic)

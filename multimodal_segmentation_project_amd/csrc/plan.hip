@@ -239,6 +239,10 @@ struct Ctx {
     mutable SlabJob pend2;
     mutable bool has_pend2 = false;
     bool defer_slabs = false;
+    // the input gradient of a block's first conv (= the gradient of the pooled tensor one level up) left as split-K partials for
+    // the MaxPool3d backward of the next segment to finish (no splitk_finish launch); pool_defer: the caller allows it
+    mutable int pool_ks = 0;
+    mutable bool pool_defer = false;
     // called before ANY launch that writes the (single) slab workspace: an older pending sum must read it first.
     // Returns where the launcher may leave its own slab sum instead of launching it (NULL: launch immediately)
     SlabJob* pend_slot() const {
@@ -391,7 +395,18 @@ int drain_aux(const Ctx& c, const float* x, void* const* grads, int accumulate, 
 
 // Fork: the queued weight gradients may start once everything the compute stream has enqueued so far is done (their dy
 // buffers are complete).  lazy: only the event is recorded here, the launches are enqueued by later drain_aux calls.
-int flush_deferred(const Ctx& c, const float* x, void* const* grads, int accumulate, bool lazy = false) {
+int flush_deferred(const Ctx& c, const float* x, void* const* grads, int accumulate, bool lazy = false, bool force = false) {
+    if (c.ndq == 0 && force) {
+        if (c.nfork >= 3) MI3D_TRY(drain_aux(c, x, grads, accumulate, -1));      // (event reuse: everything forked earlier is enqueued first)
+        // nothing queued (defer_mask), but the caller relies on the aux stream being ordered after this point of the chain
+        // (mi3d_unet_chain_tail_blocks: its optimizer tail runs there)
+        const int e = c.nfork++;
+        MI3D_HIP(hipEventRecord(c.ev[e % 3], c.s));
+        MI3D_HIP(hipStreamWaitEvent(c.s2, c.ev[e % 3], 0));
+        c.waited_ev = e;
+        c.aux_used = true;
+        return 0;
+    }
     if (c.ndq == 0) return 0;
     MI3D_CHECK_ARG(c.nfork < 3 || mi3d_routes().defer_fork_each, "flush_deferred: more than three forks in one call");
     // (fork_each: the three fork events are re-recorded in turn; a stream wait keeps the record it was issued after -- so
@@ -421,6 +436,9 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         const HalfP& H = B.h[h];
         int k = c.seq++;
         if (aux && c.nhq) MI3D_TRY(drain_aux(c, x, grads, accumulate, mi3d_routes().aux_drain));      // feed the aux stream between the chain's launches
+        // g1_fork_late: the decoder's full-resolution weight gradients start when the chain ENTERS the deep levels (first launch of
+        // the block below the last 16-wide decoder block), not beside that block's own input-gradient conv and transposed conv
+        if (aux && mi3d_routes().g1_fork_late && h == 1 && b == p.flush_b[0] - 1) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
         // deferred weight gradient: dy goes to the layer's own buffer, which nobody overwrites before the aux stream has read it
         const int dbit = H.defer == 2 ? 4 : (B.level == 0 ? 1 : 2);
         const bool dfr = aux && H.defer && (mi3d_routes().defer_mask & dbit) && (G(H.pidx) || G(H.pidx + 1));
@@ -454,18 +472,22 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
         // deferred under the current defer_mask
         auto fork_here = [&]() -> int {
             if (!aux) return 0;
-            if (mi3d_routes().defer_fork_each) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+            // defer_fork_each = 1: every deferred layer forks on its own; = 2: only the deep-level layers do (the aux stream is
+            // idle between the end of the decoder's full-resolution weight gradients and the fork behind the deep chain)
+            const int fe = mi3d_routes().defer_fork_each;
+            if (fe == 1 || (fe == 2 && H.defer == 2 && dfr)) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
             // group 1 forks when the GPU is still busy with the full-resolution decoder (the host is far ahead: enqueue at once);
             // group 2 forks at the end of the launch-bound deep chain: its launches are fed in between the chain's next ones
             for (int q = 0; q < 2; q++)
-                if (b == p.flush_b[q] && h == p.flush_h[q])
-                    MI3D_TRY(flush_deferred(c, x, grads, accumulate, q == 1 && !mi3d_routes().no_lazy_aux));
+                if (b == p.flush_b[q] && h == p.flush_h[q] && !(q == 0 && mi3d_routes().g1_fork_late))
+                    MI3D_TRY(flush_deferred(c, x, grads, accumulate, q == 1 && !mi3d_routes().no_lazy_aux, q == 1));
             return 0;
         };
         if (xf_rows == 0) MI3D_TRY(fork_here());
         if (dfr) {
             if (dx_f) {
-                const bool defer = h == 1 && c.defer_slabs && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
+                const bool to_pool = h == 0 && c.pool_defer && dx_f == dxin;
+                const bool defer = (h == 1 || to_pool) && c.defer_slabs && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
                 int ksd = 0;
                 XfArgs xb;
                 if (xf_rows > 0) {
@@ -480,7 +502,8 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
                                         (dxs_f % 8 == 0) ? c.at<float>(p.skws) : nullptr, c.s, Halves(),
                                         (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), defer ? &ksd : nullptr, 0, conv3_bwd_ks_target(),
                                         xf_rows > 0 ? &xb : nullptr));
-                if (ksd > 0) { dz_skp = c.at<float>(p.skws); dz_ks = ksd; }
+                if (ksd > 0 && h == 1) { dz_skp = c.at<float>(p.skws); dz_ks = ksd; }
+                if (ksd > 0 && h == 0) c.pool_ks = ksd;
             }
             if (xf_rows > 0) MI3D_TRY(fork_here());        // dy exists only now
             continue;
@@ -498,11 +521,13 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             SlabJob* ps = c.pend_slot();
             // half 1's input gradient feeds straight into half 0's BatchNorm-backward reduction: leave a split-K result as
             // partials and let that reduction finish it (one launch less on the chain)
-            bool defer = h == 1 && ps && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
+            const bool to_pool = h == 0 && c.pool_defer && dx_f == dxin;
+            bool defer = (h == 1 || to_pool) && ps && dxs_f % 8 == 0 && !mi3d_routes().no_defer_tail;
             int ksd = 0;
             MI3D_TRY(conv3_mfma_bwd_fused(in, ics, H.Cin, dyb, H.Cout, H.Cout, c.at(H.wpd), dx_f, dxs_f, g, G(H.pidx), G(H.pidx + 1),
                                           accumulate, c.at<float>(p.wgws), p.wgws_floats, c.at<float>(p.skws), c.s, ps,
                                           defer ? &ksd : nullptr));
+            if (ksd > 0 && h == 0) { c.pool_ks = ksd; ksd = 0; }
             c.pend_filled();
             if (ksd > 0) { dz_skp = c.at<float>(p.skws); dz_ks = ksd; }
             continue;
@@ -574,7 +599,7 @@ int block_infer(const Ctx& c, int b, const float* x) {
 
 extern "C" {
 
-int mi3d_abi_version(void) { return 4; }
+int mi3d_abi_version(void) { return 5; }
 
 int mi3d_unet_num_params(const mi3d_unet_desc* d) { return d ? 8 * (2 * d->n_levels + 1) + 2 * d->n_levels + 2 : -1; }
 int mi3d_unet_num_buffers(const mi3d_unet_desc* d) { return d ? 6 * (2 * d->n_levels + 1) : -1; }
@@ -624,6 +649,43 @@ static LossCfg cfg_of(const mi3d_loss_cfg* c) {
     return k;
 }
 
+// MFMA weight images of the DoubleConv blocks [b0, b1) (+ the transposed convs) of the training forward / backward, one launch
+static int pack_training_weights(const Ctx& c, int b0, int b1, bool upconvs) {
+    const Plan& p = c.p;
+    PackJobs J;
+    J.n = 0; J.nblocks = 0;
+    for (int b = b0; b < b1 && b < p.nblk; b++)
+        for (int h = 0; h < 2; h++) {
+            const HalfP& H = p.blk[b].h[h];
+            if (H.mfma) MI3D_TRY(pack_all_add_conv3(J, c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), p.geo[p.blk[b].level]));
+        }
+    if (upconvs)
+        for (int i = 0; i < p.L; i++) {
+            int l = p.L - 1 - i;
+            if (p.up_mfma[i]) MI3D_TRY(pack_all_add_upconv(J, c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i])));
+        }
+    return pack_all_launch(J, c.s);
+}
+
+extern "C" int mi3d_unet_pack_from(const mi3d_unet_desc* d, const void* const* params, void* workspace, size_t workspace_bytes,
+                                   int first_block, void* stream) {
+    Plan p;
+    MI3D_TRY(build_plan(d, p));
+    MI3D_CHECK_ARG(params && workspace && workspace_bytes >= p.total && first_block >= 0, "mi3d_unet_pack_from: bad arguments");
+    Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
+    return pack_training_weights(c, first_block, p.nblk, true);
+}
+
+// leading encoder blocks whose weight gradients stay on the data-gradient chain (no deferred layer), i.e. are produced last
+extern "C" int mi3d_unet_chain_tail_blocks(const mi3d_unet_desc* d) {
+    Plan p;
+    if (!d || build_plan(d, p) != 0) return 0;
+    if (mi3d_routes().no_defer_wgrad || p.flush_b[1] < 0) return 0;      // no fork behind the deep levels: the aux stream is not ordered
+    int k = 0;
+    while (k < p.L && p.blk[k].h[0].defer == 0 && p.blk[k].h[1].defer == 0) k++;
+    return (k < p.L) ? k : 0;
+}
+
 static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* buffers,
                       const float* drop_scales, int training, float* logits, float* gap_out, void* workspace,
                       size_t workspace_bytes, void* stream, const HeadLoss* hl) {
@@ -636,21 +698,10 @@ static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void
     int L = p.L;
     if (d->in_channels > 1)
         MI3D_TRY(ncdhw_to_ndhwc(p.dt, x, c.at(p.xcl), d->in_channels, d->in_channels, d->N, p.geo[0].V(), c.s));
-    {   // every MFMA weight pack of the network in one launch
-        PackJobs J;
-        J.n = 0; J.nblocks = 0;
-        for (int b = 0; b < p.nblk; b++)
-            for (int h = 0; h < 2; h++) {
-                const HalfP& H = p.blk[b].h[h];
-                if (H.mfma) MI3D_TRY(pack_all_add_conv3(J, c.P(H.pidx), H.Cin, H.Cout, c.at(H.wpf), c.at(H.wpd), p.geo[p.blk[b].level]));
-            }
-        for (int i = 0; i < L; i++) {
-            int l = L - 1 - i;
-            if (p.up_mfma[i]) MI3D_TRY(pack_all_add_upconv(J, c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i])));
-        }
-        MI3D_TRY(pack_all_launch(J, c.s));
-        c.packed = true;
-    }
+    // every MFMA weight pack of the network in one launch (prepacked_from = k > 0: the caller's mi3d_unet_pack_from already did
+    // the blocks >= k and the transposed convs behind its optimizer update)
+    MI3D_TRY(pack_training_weights(c, 0, d->prepacked_from > 0 ? d->prepacked_from : p.nblk, d->prepacked_from <= 0));
+    c.packed = true;
     for (int l = 0; l < L; l++) {
         // fused apply + pool: even sides (every voxel in exactly one window) and 32-bit element indices
         const bool even = p.geo[l].D % 2 == 0 && p.geo[l].H % 2 == 0 && p.geo[l].W % 2 == 0 &&
@@ -890,13 +941,21 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
         } else if (seg == L + 1) {
             if (dgap)
                 MI3D_TRY(gap_bwd(p.dt, dgap, gap_scale, c.at(p.gz[L]), p.C[L], p.C[L], d->N, p.geo[L].V(), dlogits ? 1 : 0, c.s));
+            // (the gradient of the pooled tensor may stay split-K partials when the MaxPool3d backward that reads it is launched
+            // by this very call: a later call would not know about them)
+            c.pool_defer = seg + 1 < seg_end && !mi3d_routes().no_pool_splitk;
             MI3D_TRY(block_backward(c, L, x, grads, drop_scales, c.at(p.gz[L]), p.C[L], c.at(p.gp[L - 1]), p.C[L - 1], accumulate));
+            c.pool_defer = false;
         } else {
             int l = 2 * L + 1 - seg;              // encoder.l
             MI3D_TRY(maxpool2_bwd(p.dt, c.at(p.gp[l]), p.C[l], c.at(p.cat[l]), p.catcs(l), dlogits ? c.at(p.gcat[l]) : nullptr,
-                                  p.catcs(l), c.at(p.gz[l]), p.C[l], p.C[l], p.geo[l], c.s));
+                                  p.catcs(l), c.at(p.gz[l]), p.C[l], p.C[l], p.geo[l], c.s,
+                                  c.pool_ks > 0 ? c.at<float>(p.skws) : nullptr, c.pool_ks));
+            c.pool_ks = 0;
             void* dx = l > 0 ? c.at(p.gp[l - 1]) : nullptr;
+            c.pool_defer = l > 0 && seg + 1 < seg_end && !mi3d_routes().no_pool_splitk;
             MI3D_TRY(block_backward(c, l, x, grads, drop_scales, c.at(p.gz[l]), p.C[l], dx, l > 0 ? p.C[l - 1] : 0, accumulate));
+            c.pool_defer = false;
         }
     }
     MI3D_TRY(c.flush_pend());

@@ -40,7 +40,10 @@ __global__ __launch_bounds__(BLK) void maxpool2_fwd_kernel(const T* __restrict__
 template <typename T, int VEC>
 __global__ __launch_bounds__(BLK) void maxpool2_bwd_kernel(const T* __restrict__ dp, int dpcs, const T* __restrict__ z, int zcs,
                                                            const T* __restrict__ dskip, int dskipcs, T* __restrict__ dz,
-                                                           int dzcs, int C, int N, int D, int H, int W) {
+                                                           int dzcs, int C, int N, int D, int H, int W,
+                                                           const float* __restrict__ skp, int ks) {
+    // skp != NULL: dp is still the ks fp32 split-K partials [ks][Mp][C] of the input-gradient conv that produced it; they are
+    // summed in order and rounded to T here (what splitk_finish_kernel would have stored): its launch disappears
     int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
     int64_t total = (int64_t)N * Do * Ho * Wo * G;
     for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
@@ -59,7 +62,19 @@ __global__ __launch_bounds__(BLK) void maxpool2_bwd_kernel(const T* __restrict__
 #pragma unroll
             for (int i = 0; i < VEC; i++) if (v[k][i] > m[i]) { m[i] = v[k][i]; arg[i] = k; }
         }
-        ldv<T, VEC>(dp + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * dpcs + g * VEC, gp);
+        if (skp) {
+            const int64_t row = (((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo, Mp = (int64_t)N * Do * Ho * Wo;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) gp[i] = 0.f;
+            for (int k = 0; k < ks; k++) {
+                const float* pp = skp + ((int64_t)k * Mp + row) * C + g * VEC;
+#pragma unroll
+                for (int i = 0; i < VEC; i++) gp[i] += pp[i];
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; i++) gp[i] = round_to<T>(gp[i]);
+        } else
+            ldv<T, VEC>(dp + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * dpcs + g * VEC, gp);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             int a = k >> 2, b = (k >> 1) & 1, c = k & 1;
@@ -157,7 +172,8 @@ int maxpool2_fwd(int dtype, const void* z, int zcs, int C, Geo g, void* p, int p
 }
 
 int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, const void* dskip, int dskipcs, void* dz,
-                 int dzcs, int C, Geo g, hipStream_t s) {
+                 int dzcs, int C, Geo g, hipStream_t s, const float* skp, int ks) {
+    if (ks <= 0) skp = nullptr;
     MI3D_CHECK_ARG(g.D >= 2 && g.H >= 2 && g.W >= 2, "maxpool2_bwd: volume too small");
     MI3D_CHECK_ARG(g.M() / 8 * C < (1ll << 31), "maxpool2_bwd: more than 2^31 pooled elements");
     int64_t nout = (int64_t)g.N * (g.D / 2) * (g.H / 2) * (g.W / 2);
@@ -166,9 +182,9 @@ int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, co
         bool v8 = C % 8 == 0 && zcs % 8 == 0 && dpcs % 8 == 0 && dzcs % 8 == 0 && (!dskip || dskipcs % 8 == 0) &&
                   al16(z) && al16(dp) && al16(dz) && al16(dskip);
         if (v8)
-            maxpool2_bwd_kernel<T, 8><<<sgrid(nout * (C / 8)), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);
+            maxpool2_bwd_kernel<T, 8><<<sgrid(nout * (C / 8)), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W, skp, ks);
         else
-            maxpool2_bwd_kernel<T, 1><<<sgrid(nout * C), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);
+            maxpool2_bwd_kernel<T, 1><<<sgrid(nout * C), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W, skp, ks);
         MI3D_LAUNCH_CHECK();
         if (odd) {
             maxpool2_bwd_border_kernel<T><<<sgrid(g.M()), BLK, 0, s>>>((const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W);

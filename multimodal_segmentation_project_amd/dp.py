@@ -128,6 +128,8 @@ class DataParallelComm:
             self.average_(self.arena.g[r[0]:r[1]])
             if self.emulate is not None and self.arena.g.is_cuda:
                 from ._lib import call, stream_ptr
-                g = self.arena.g[r[0]:r[1]]
+                if getattr(self, "_emulate_buf", None) is None:          # the stand-in's own scratch, never the gradient arena
+                    self._emulate_buf = torch.zeros(1 << 20, dtype=torch.float32, device=self.arena.g.device)
                 usec = max(1, int(self.emulate[1] * (r[1] - r[0]) / self.arena.numel))      # duration ~ bytes exchanged
-                call("mi3d_debug_occupy_cus", self.emulate[0], usec, g.data_ptr(), g.numel(), stream_ptr())
+                call("mi3d_debug_occupy_cus", self.emulate[0], usec, self._emulate_buf.data_ptr(), self._emulate_buf.numel(),
+                     stream_ptr())

@@ -59,14 +59,25 @@ def _priority_stream(device, cls):
     return st
 
 
-def concurrent_stream(device, candidates=6, hold_us=300, priority="high"):
+_STREAM_CACHE = {}      # (device index, priority, role) -> stream chosen by concurrent_stream
+
+
+def concurrent_stream(device, candidates=6, hold_us=300, priority="high", role="aux"):
     """A stream whose kernels really run BESIDE those of the current (compute) stream.  HIP multiplexes streams onto a few
     hardware queues, and two streams that share a queue execute strictly one after the other (measured with rocprofv3: the
     default stream and the 8th stream created in a process both sat on queue 4, and a collective kernel on the latter ran
-    between, not beside, the backward kernels -- profiles/r03_dp_streams.txt).  So the communication stream is CHOSEN by a
-    measurement: a stand-in kernel that holds a few workgroups for `hold_us` is launched on the candidate and on the compute
-    stream; if the pair takes about one hold time they overlap.  The first candidate has high priority (its own queue on this
-    runtime).  Falls back to the last candidate, with a warning attribute, when none overlaps."""
+    between, not beside, the backward kernels -- profiles/r03_dp_streams.txt).  So the stream is CHOSEN by a measurement: a
+    stand-in kernel that holds a few workgroups for `hold_us` is launched on the candidate and on the compute stream; if the
+    pair takes about one hold time they overlap (minimum of three timed repetitions: a busy GPU only ever makes a pair look
+    slower).  The first candidate has the requested priority class ("high": its own queue on this runtime; "low": the lowest
+    class, mi3d_stream_create).  The choice is cached per (device, priority, role): every step object of a process shares it
+    and the probe runs once.  When no candidate overlaps, the last one is returned with mi3d_concurrent = False and a
+    RuntimeWarning: the step is still correct, only nothing will run beside the compute stream."""
+    import warnings
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), priority, role)
+    if key in _STREAM_CACHE:
+        return _STREAM_CACHE[key]
     main = torch.cuda.current_stream(device)
     buf = torch.zeros(1024, dtype=torch.float32, device=device)
     best = None
@@ -78,7 +89,7 @@ def concurrent_stream(device, candidates=6, hold_us=300, priority="high"):
         else:
             c = torch.cuda.Stream(device=device)
         times = []
-        for rep in range(2):                       # first pass loads the code object
+        for rep in range(4):                       # first pass loads the code object
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(device)
             e0.record(main)
@@ -89,11 +100,16 @@ def concurrent_stream(device, candidates=6, hold_us=300, priority="high"):
             e1.record(main)
             e1.synchronize()
             times.append(e0.elapsed_time(e1) * 1e3)
-        c.mi3d_overlap_us = times[-1]
-        c.mi3d_concurrent = times[-1] < 1.5 * hold_us
+        c.mi3d_overlap_us = min(times[1:])
+        c.mi3d_concurrent = c.mi3d_overlap_us < 1.5 * hold_us
         best = c
         if c.mi3d_concurrent:
             break
+    if not best.mi3d_concurrent:
+        warnings.warn(f"concurrent_stream: none of {candidates} candidate streams ran beside the compute stream on {dev} "
+                      f"(pair time {best.mi3d_overlap_us:.0f} us for 2 x {hold_us} us): aux-stream work will serialise",
+                      RuntimeWarning, stacklevel=2)
+    _STREAM_CACHE[key] = best
     return best
 
 
@@ -152,7 +168,7 @@ class _StepBase:
         self.comm = DataParallelComm(self.arena, n_levels, process_group, force=self.do_comm,
                                      fine_buckets=os.environ.get("MI3D_FINE_BUCKETS", "0") == "1")
         # the exchange stream must sit on another hardware queue than the compute stream (see concurrent_stream)
-        self.comm_stream = concurrent_stream(self.device) if self.do_comm else None
+        self.comm_stream = concurrent_stream(self.device, role="comm") if self.do_comm else None
         self.use_graph = bool(use_graph)
         self._statics = {}
         self._static = None
@@ -217,6 +233,10 @@ class _StepBase:
 
     def _join_comm(self):
         torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _param_versions(self):
+        """Sum of the version counters of the model's Parameters (each is a view of the arena with its OWN counter)."""
+        return sum(p._version for p in self.arena.params)
 
     def _adamw(self, arena, ranges, hyper, s):
         lr, b1, b2, eps, wd = hyper
@@ -321,7 +341,7 @@ class TrainStep(_StepBase):
         """aux_wgrad: the backward's critical path is the input-gradient chain alone -- the weight gradients of the decoder's
         full-resolution convs and of all deep-level convs run on a second stream (include/mi3d.h, mi3d_unet_backward: aux_stream),
         forked from the chain at most three times and joined in front of the optimizer; bit-identical results.  None (default):
-        on for eager launches, off under use_graph -- this runtime's hipGraph executor spreads a forked graph over three hardware
+        on for eager launches without a gradient exchange, off under use_graph -- this runtime's hipGraph executor spreads a forked graph over three hardware
         queues and replays it at half speed (4.4 vs 2.2 ms, profiles/r04_defer_graph_streams.txt), eager launches do not.
         keep_logits: the step folds the 1x1x1 head into the loss and never writes the logits (mi3d_unet_forward_loss); True
         keeps a copy in the static buffer `logits` for callers that read them after step().
@@ -346,11 +366,14 @@ class TrainStep(_StepBase):
         # its own stream beside the student forward (fork after the batch is in place, join in front of the loss; both
         # branches are captured into the one step graph).  Separate workspaces and logits: results are bitwise those of the
         # serial order.  Both forwards are long chains that leave most CUs idle at the deep levels, so they interleave.
-        self.kd_stream = concurrent_stream(self.device) if (kd_teacher is not None and overlap_teacher) else None
+        self.kd_stream = concurrent_stream(self.device, role="kd") if (kd_teacher is not None and overlap_teacher) else None
         # second compute stream: the deferred weight-gradient kernels run beside the data-gradient chain (mi3d_unet_backward)
         # (priority classes measured at 96^3, eager: high 2.111 / normal 2.121 / low 2.124 ms -- profiles/r04_experiments_aux_wgrad.txt)
         if aux_wgrad is None:
-            aux_wgrad = not use_graph
+            # not with a gradient exchange either: the deferred deep-level weight gradients are 95 % of the gradient bytes and
+            # finish ~150 us before the end of the backward, so the big all-reduce bucket (dp.bucket_ranges) would lose the
+            # 0.45 ms of encoder backward it hides under; the exchange is worth more than the ~20 us the deferral buys
+            aux_wgrad = not use_graph and not self.do_comm
         self.aux_stream = (concurrent_stream(self.device, priority=os.environ.get("MI3D_AUX_PRIO", "high")) if aux_wgrad else None)
         self._events = None
         self._event_handles = []
@@ -461,6 +484,11 @@ class TrainStep(_StepBase):
                 st["t_logits"] = torch.empty_like(st["logits"])
                 st["t_ptab"] = ptr_table([p.data_ptr() for p in self.teacher.parameters()])
                 st["t_btab"] = ptr_table([b.data_ptr() for b in self.teacher.buffers()])
+            if st["fused_head"] and not self.keep_logits:
+                # the fused head never writes logits / dlogits: there is no buffer to read stale values from (ts._static["logits"]
+                # is None; keep_logits=True keeps a copy)
+                st["logits"] = None
+                st["dlogits"] = None
             self._static = st
         self._statics[key] = st
         return st
@@ -502,6 +530,12 @@ class TrainStep(_StepBase):
         n, c, v = desc.N, desc.out_channels, desc.D * desc.H * desc.W
         fused = st["fused_head"]
         keep = ptr(st["logits"]) if self.keep_logits else None
+        # weight packs the last optimizer tail already refreshed on the aux stream (valid only while nobody has written the
+        # parameters through torch since: load_state_dict, a torch optimizer, any in-place op on a Parameter bump its version
+        # counter; writes through `.data` or raw pointers do not -- set ts._static["prepacked"] = None after such a write)
+        pre = st.get("prepacked")
+        desc.prepacked_from = (pre[0] if (pre and pre[2] == getattr(self, "_param_epoch", 0) and pre[1] == self._param_versions())
+                               else 0)        # (the epoch: another static state of this object -- another batch shape -- may have stepped since)
         if fused and self.teacher is None:
             # 1x1x1 head + loss + metrics in one pass: the logits are never written (mi3d.h, mi3d_unet_forward_loss)
             call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["btab"], ptr(drop), 1, ptr(st["y"]), None,
@@ -544,6 +578,13 @@ class TrainStep(_StepBase):
             do_comm = self.do_comm and boundary
             aux = self.aux_stream.cuda_stream if self.aux_stream is not None else None
             aux_open = False        # aux-stream work of an earlier call that nothing on the compute stream has waited for yet
+            # optimizer tail on the aux stream (include/mi3d.h, mi3d_unet_chain_tail_blocks): without a gradient exchange the whole
+            # backward is ONE C call; with aux_join = 0 the aux stream ends up ordered after every gradient except those of the
+            # leading `tail_k` encoder blocks, which the compute stream produces last
+            tail_k = 0
+            if (aux is not None and boundary and not do_comm and not self.use_graph and nseg == 2 * st["L"] + 2
+                    and _lib.get_route("opt_tail")):
+                tail_k = _lib.lib().mi3d_unet_chain_tail_blocks(C.byref(desc))
             # one C call per run of segments between exchange steps: kernels of adjacent segments share launches (a
             # weight-gradient slab sum rides in the next BatchNorm reduction), which a call boundary would cut
             start = 0
@@ -561,8 +602,8 @@ class TrainStep(_StepBase):
                     # that is followed by a gradient exchange leaves the join to the exchange stream (_on_comm_stream), so the
                     # deep-level weight gradients keep running under the next segments.  Segmented graphs end a capture at every
                     # exchange: there every call joins
-                    join = 1 if (last or self.use_graph or aux is None) else 0
-                    aux_open = aux_open or (aux is not None and not join)
+                    join = 1 if ((last and not tail_k) or self.use_graph or aux is None) else 0
+                    aux_open = aux_open or (aux is not None and not join and not tail_k)
                     if fused:
                         call("mi3d_unet_backward_loss", C.byref(desc), ptr(st["x"]), st["ptab"], st["gtab"], ptr(drop),
                              ptr(st["y"]), ptr(t_logits), C.byref(self.cfg), ptr(st["coef"]), ptr(self.inv_accum), None, 1.0,
@@ -594,8 +635,30 @@ class TrainStep(_StepBase):
             comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
         if self.do_comm and not joined:
             comm(self._join_comm)
-        if boundary:
+        if boundary and run_backward and self.aux_stream is not None and tail_k > 0:
+            # AdamW over everything but the leading blocks + the re-pack of those weights for the next forward run on the aux
+            # stream, behind the deferred weight gradients and beside the compute stream's last (full-resolution encoder) backward
+            # kernels; the compute stream joins and updates the leading blocks.  Same arithmetic per parameter, same step count.
+            cut = self.arena.offsets[8 * tail_k]
+            r_a = [(max(lo, cut), hi) for lo, hi in st["opt_ranges"] if hi > cut]
+            r_b = [(lo, min(hi, cut)) for lo, hi in st["opt_ranges"] if lo < cut]
+            hyper = self._hyper()
+            with torch.cuda.stream(self.aux_stream):
+                a = self.aux_stream.cuda_stream
+                lr, b1, b2, eps, wd = hyper
+                for lo, hi in r_a:
+                    call("mi3d_adamw_apply", self.arena.p.data_ptr() + 4 * lo, self.arena.g.data_ptr() + 4 * lo,
+                         self.arena.m.data_ptr() + 4 * lo, self.arena.v.data_ptr() + 4 * lo, hi - lo, lr, b1, b2, eps, wd, 1.0,
+                         ptr(self.arena.step), 0, a)
+                call("mi3d_unet_pack_from", C.byref(desc), st["ptab"], ptr(st["ws"]), st["ws_bytes"], tail_k, a)
+            torch.cuda.current_stream().wait_stream(self.aux_stream)
+            self._adamw(self.arena, r_b if r_b else [(0, 0)], hyper, s)
+            self._param_epoch = getattr(self, "_param_epoch", 0) + 1
+            st["prepacked"] = (tail_k, self._param_versions(), self._param_epoch)
+        elif boundary:
             self._adamw(self.arena, st["opt_ranges"], self._hyper(), s)
+            self._param_epoch = getattr(self, "_param_epoch", 0) + 1
+            st["prepacked"] = None
 
     def step(self, images, labels, last_batch=False):
         """One micro-step on (images (N,Cin,D,H,W) float, labels (N,1,D,H,W) int64).  Returns a device float32[4]
@@ -675,7 +738,7 @@ class DannStep(_StepBase):
         # Both are forwards of ONE model in train mode, i.e. both update the same BatchNorm running statistics, source first:
         # the target forward runs with the update DEFERRED (mi3d_unet_forward training = 2 publishes its batch statistics as
         # doubles) and mi3d_unet_bn_apply_deferred applies it after the join -- buffers bit-identical to the serial order.
-        self.fwd_stream = concurrent_stream(self.device) if overlap_forwards else None
+        self.fwd_stream = concurrent_stream(self.device, role="fwd") if overlap_forwards else None
         self.disc = disc_model
         self.lam = float(lambda_domain)
         self.cfg = _loss_cfg(loss)

@@ -135,3 +135,38 @@ def test_apply_on_load_with_dropout_masks(routes):
     for a, b in zip(o0, o1):
         assert torch.equal(a, b), (a, b)
     assert torch.equal(g0, g1) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("size", [96, 32])
+def test_optimizer_tail_on_the_aux_stream_is_bitwise_the_serial_tail(routes, size):
+    """Eager step with aux-stream weight gradients: AdamW over everything but the leading (full-resolution) encoder blocks and
+    the re-pack of those weights run on the aux stream beside the end of the backward, the compute stream updates the leading
+    blocks behind the join, and the next forward packs only them (desc.prepacked_from).  Against the default (opt_tail = 0: whole update and
+    all packs on the compute stream): metrics of every step, parameters, AdamW moments, step count, BatchNorm buffers bit for
+    bit over four steps -- including a step after the parameters were changed THROUGH TORCH between two steps (the arena's
+    version counter must invalidate the pre-packed weights: stale packs would show in the very next loss)."""
+    x, y = synth(2, size, 31, blocky=True)
+    res = []
+    for off in (0, 1):
+        routes.set("opt_tail", 1 - off)
+        m = default_model().to(DEV).train()
+        ts = TrainStep(m, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=False, aux_wgrad=True)
+        ts.load_batch(x.to(DEV), y.to(DEV))
+        outs = [ts.step_static().clone() for _ in range(2)]
+        if off == 0:
+            assert ts._static.get("prepacked") is not None and ts._static["prepacked"][0] >= 1
+        with torch.no_grad():
+            m.bottleneck.double_conv[0].weight.mul_(1.25)          # a deep-level weight, re-packed by the aux tail route
+            m.decoder[3].double_conv[4].weight.add_(0.01)
+        outs += [ts.step_static().clone() for _ in range(2)]
+        torch.cuda.synchronize()
+        res.append((outs, ts.arena.p.clone(), ts.arena.m.clone(), ts.arena.v.clone(), ts.arena.step.clone(), [b.clone() for b in m.buffers()]))
+        ts.close()
+    routes.reset("opt_tail")
+    (o0, p0, m0, v0, s0, b0), (o1, p1, m1, v1, s1, b1) = res
+    for i, (a, b) in enumerate(zip(o0, o1)):
+        assert torch.equal(a, b), (i, a, b)
+    assert float(o0[2][0]) != float(o0[1][0])
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(s0, s1)
+    for a, b in zip(b0, b1):
+        assert torch.equal(a, b)

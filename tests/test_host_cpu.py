@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib._SIGS, f"_lib.py does not bind {name}"
         assert len(_lib._SIGS[name][1]) == nargs, f"{name}: header has {nargs} args, binding {len(_lib._SIGS[name][1])}"
     assert set(_lib._SIGS) == set(fns)
-    assert lib.mi3d_abi_version() == 4
+    assert lib.mi3d_abi_version() == 5
 
 
 def test_state_dict_surface_matches_reference(golden):

@@ -6,8 +6,8 @@ gfx950) into per-kernel HBM traffic, corrected as /opt/skills/guides/MI355X_MICR
     kernels whose reads are all 16-B vector loads (every kernel here stages/streams with dwordx4 loads);
   * WRITE_SIZE is exact for 16-B-per-lane stores.
 Usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [--step <step_out.json>]
-  --step: additionally sum the dispatches of the LAST complete training step (delimited by pack_all_kernel, the first
-  launch of a forward) and write per-dispatch + whole-step HBM bytes (to compare with the 4.84 GB algorithmic model)."""
+  --step: additionally sum the dispatches of the LAST complete training step (delimited by conv3_c1_fwd_mfma_kernel, the first
+  conv of a forward) and write per-dispatch + whole-step HBM bytes (to compare with the 4.84 GB algorithmic model)."""
 import collections
 import csv
 import glob
@@ -39,7 +39,7 @@ def step_summary(fd, wd, out):
 
     def last_step(agg):
         ids = sorted(agg)
-        starts = [i for i in ids if "pack_all" in agg[i][0]]
+        starts = [i for i in ids if "conv3_c1_fwd_mfma" in agg[i][0]]
         return [i for i in ids if starts[-2] <= i < starts[-1]]
 
     fi, wi = last_step(fa), last_step(wa)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of ONE training step from a rocprofv3 --kernel-trace CSV: every kernel node of the last complete step
-(steps are delimited by pack_all_kernel, the first launch of a forward) with its duration and the idle gap before it.
+(steps are delimited by conv3_c1_fwd_mfma_kernel, the first conv of a forward: once per step) with its duration and the idle gap before it.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python bench.py --steps 6 --warmup 3 ...
     python tools/trace_step.py gpurun_out/trace [--out profiles/rNN_step_timeline.txt]
@@ -26,7 +26,7 @@ def main():
     f = sorted(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True))[-1]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "pack_all_kernel" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "conv3_c1_fwd_mfma_kernel" in r["Kernel_Name"]]
     if len(starts) < 3:
         print("not enough steps in trace", len(starts))
         return

@@ -17,7 +17,7 @@ def main():
     f = sorted(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True))[-1]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "pack_all_kernel" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "conv3_c1_fwd_mfma_kernel" in r["Kernel_Name"]]
     if len(starts) < 3:
         print("not enough steps in trace", len(starts))
         return
