@@ -125,6 +125,21 @@ int mi3d_unet_backward(const mi3d_unet_desc* d, const float* x, const void* cons
 int mi3d_unet_chain_tail_blocks(const mi3d_unet_desc* d);
 int mi3d_unet_pack_from(const mi3d_unet_desc* d, const void* const* params, void* workspace, size_t workspace_bytes,
                         int first_block, void* stream);
+/* Exchange marks (data-parallel step, round 4): events[i] is recorded on the backward's stream as soon as every gradient of the
+ * segments <= segs[i] is complete -- set for the NEXT mi3d_unet_backward / _backward_loss call of the calling thread (n <= 4,
+ * n = 0 clears).  The backward then stays ONE call over all segments (a call cut at an exchange costs a slab-sum launch and a
+ * host round trip); the exchange stream waits for the mark (mi3d_stream_wait_event) and all-reduces the bucket while the
+ * remaining segments run.  Marks are consumed by that call. */
+int mi3d_unet_backward_marks(const int* segs, void* const* events, int n);
+/* Stream-to-stream ordering through a counter in device memory (flag = device int64[2], zero-initialised by the caller): a
+ * hardware cross-queue wait costs the waiting stream 30-45 us on this runtime even for an event that fired long ago.
+ * mi3d_flag_set: flag[0] = value once everything enqueued on `stream` so far has finished (one 1-thread kernel).
+ * mi3d_flag_wait: `stream` continues when flag[0] >= value (one 1-wave kernel that polls; values must grow monotonically, e.g. a
+ * step counter).  After timeout_us without it the waiter gives up and stores `value` in flag[1]: a caller that cannot rule out a
+ * lost producer checks flag[1] afterwards.  Use only where the producing stream cannot depend on the waiting one. */
+int mi3d_flag_set(int64_t* flag, int64_t value, void* stream);
+int mi3d_flag_wait(int64_t* flag, int64_t value, int64_t timeout_us, void* stream);
+int mi3d_stream_wait_event(void* stream, void* event);
 int mi3d_event_create(void** event_out);
 int mi3d_event_destroy(void* event);
 /* A non-blocking hipStream_t of a priority class: -1 = the device's highest, 0 = middle, +1 = lowest.  torch.cuda.Stream only

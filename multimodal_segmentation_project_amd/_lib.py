@@ -58,6 +58,10 @@ _SIGS = {
     "mi3d_unet_backward": (i32, [_DP, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, vp, sz, vp, vp, vp, i32]),
     "mi3d_unet_chain_tail_blocks": (i32, [_DP]),
     "mi3d_unet_pack_from": (i32, [_DP, C.POINTER(vp), vp, sz, i32, vp]),
+    "mi3d_unet_backward_marks": (i32, [C.POINTER(C.c_int), C.POINTER(vp), i32]),
+    "mi3d_stream_wait_event": (i32, [vp, vp]),
+    "mi3d_flag_set": (i32, [vp, C.c_int64, vp]),
+    "mi3d_flag_wait": (i32, [vp, C.c_int64, C.c_int64, vp]),
     "mi3d_event_create": (i32, [C.POINTER(vp)]),
     "mi3d_event_destroy": (i32, [vp]),
     "mi3d_stream_create": (i32, [i32, C.POINTER(vp)]),

@@ -117,6 +117,14 @@ int mi3d_adamw_apply(float* p, const float* g, float* m, float* v, int64_t n, fl
     MI3D_CHECK_ARG(step_dev && (n == 0 || (p && g && m && v)) && n >= 0, "mi3d_adamw_apply: bad arguments");
     return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step_dev, (hipStream_t)stream, increment);
 }
+int mi3d_flag_set(int64_t* flag, int64_t value, void* stream) {
+    MI3D_CHECK_ARG(flag, "mi3d_flag_set: null flag");
+    return flag_set(flag, value, (hipStream_t)stream);
+}
+int mi3d_flag_wait(int64_t* flag, int64_t value, int64_t timeout_us, void* stream) {
+    MI3D_CHECK_ARG(flag && timeout_us > 0, "mi3d_flag_wait: bad arguments");
+    return flag_wait(flag, value, timeout_us, (hipStream_t)stream);
+}
 int mi3d_debug_occupy_cus(int workgroups, int microseconds, float* buf, int64_t n, void* stream) {
     return occupy_cus(workgroups, microseconds, buf, n, (hipStream_t)stream);
 }
@@ -352,7 +360,11 @@ const char* mi3d_debug_route_name(int i) { return (i >= 0 && i < N_ROUTES) ? ROU
 int mi3d_event_create(void** event_out) {
     MI3D_CHECK_ARG(event_out, "mi3d_event_create: null output");
     hipEvent_t e;
-    MI3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // no system-scope fence on record: by default hipEventRecord writes the caches back for the HOST's benefit, which costs the
+    // recording stream tens of microseconds in the middle of a kernel chain (round 4: one mid-backward record = +43 us/step).
+    // These events only order streams of ONE device; the producing kernel's own end-of-kernel release covers that.
+    static const bool sysfence = getenv("MI3D_EVENT_SYSFENCE") != nullptr;        // diagnostic: the old behaviour
+    MI3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence)));
     *event_out = (void*)e;
     return 0;
 }

@@ -357,6 +357,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(128))) void occ
     }
     asm volatile("" :: "v"(acc));                      // keep the loads alive without writing anything
 }
+// ---- stream-to-stream ordering through a memory flag ------------------------------------------------------------------------
+// A hardware cross-queue dependency (hipStreamWaitEvent on an event of another hardware queue) costs the WAITING stream 30-45 us on
+// this runtime even when the event fired long ago (profiles/r04_experiments_dp_marks.txt: fork + join around NOTHING = +47 us per
+// step).  Where the producer is known to finish early -- the big gradient bucket's all-reduce ends ~400 us before the backward does
+// -- the consumer polls a counter in memory instead: the producing stream bumps it behind its last kernel (that kernel's end has
+// made its writes visible device-wide), the consuming stream runs a one-wave kernel that returns as soon as the counter has reached
+// the value.  Bounded: after `timeout_us` the waiter gives up and raises the error word (flag[1]), which the host checks lazily.
+__global__ void flag_set_kernel(long long* flag, long long value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void flag_wait_kernel(long long* flag, long long value, long long timeout_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+        if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > timeout_ticks) {
+            __hip_atomic_store(flag + 1, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // timed out waiting for `value`
+            return;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+int flag_set(int64_t* flag, int64_t value, hipStream_t s) {
+    flag_set_kernel<<<1, 1, 0, s>>>((long long*)flag, (long long)value);
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+int flag_wait(int64_t* flag, int64_t value, int64_t timeout_us, hipStream_t s) {
+    flag_wait_kernel<<<1, 64, 0, s>>>((long long*)flag, (long long)value, (long long)timeout_us * 100);     // s_memrealtime: 100 MHz
+    MI3D_LAUNCH_CHECK();
+    return 0;
+}
+
 int occupy_cus(int wgs, int usec, float* buf, int64_t n, hipStream_t s) {
     MI3D_CHECK_ARG(wgs >= 1 && wgs <= 256 && usec >= 1 && usec <= 5000, "occupy_cus: wgs in [1,256], usec in [1,5000]");
     occupy_kernel<<<wgs, 512, 0, s>>>(buf, n, usec);

@@ -269,6 +269,8 @@ int adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr
 // Dropout3d channel masks: out[i] = (u_i >= p) ? 1/(1-p) : 0, counter-based RNG; state_dev = {seed, counter}
 int dropout_scales(float* out, int64_t n, float p, uint64_t* state_dev, hipStream_t s);
 int fill_f32(float* p, int64_t n, float v, hipStream_t s);
+int flag_set(int64_t* flag, int64_t value, hipStream_t s);                      // flag[0] = value behind everything enqueued on s
+int flag_wait(int64_t* flag, int64_t value, int64_t timeout_us, hipStream_t s);   // s continues when flag[0] >= value (flag[1] = value on time-out)
 int occupy_cus(int wgs, int usec, float* buf, int64_t n, hipStream_t s);     // collective stand-in (bench.py --emulate-comm)
 int scale_f32(const float* x, float* y, int64_t n, float a, const float* a_dev, hipStream_t s);   // y = a * (*a_dev|1) * x
 int scale_add_f32(float* dst, const float* src, int64_t n, float a, float b, hipStream_t s);  // dst = a*dst + b*src

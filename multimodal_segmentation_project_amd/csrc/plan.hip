@@ -243,6 +243,7 @@ struct Ctx {
     // the MaxPool3d backward of the next segment to finish (no splitk_finish launch); pool_defer: the caller allows it
     mutable int pool_ks = 0;
     mutable bool pool_defer = false;
+    mutable hipEvent_t mark_pending = nullptr;      // exchange mark waiting for the launch that completes its segment's gradients
     // called before ANY launch that writes the (single) slab workspace: an older pending sum must read it first.
     // Returns where the launcher may leave its own slab sum instead of launching it (NULL: launch immediately)
     SlabJob* pend_slot() const {
@@ -460,6 +461,7 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
                         h == 0 ? dz_ks : 0, (c.has_pend && c.has_pend2) ? &c.pend2 : nullptr, want_xf ? &xf_rows : nullptr));
         c.has_pend = false;
         c.has_pend2 = false;
+        if (c.mark_pending) { MI3D_HIP(hipEventRecord(c.mark_pending, c.s)); c.mark_pending = nullptr; }      // the slab sums of the marked segment rode in this launch
         if (dfr) {
             // the chain runs the input-gradient conv alone; the weight gradient is queued for the aux stream.  Its slab partition
             // is the fused launch's (conv3_mfma_bwd_wg_target), the input gradient uses the fused launch's split-K factor and the
@@ -869,6 +871,24 @@ int mi3d_unet_infer(const mi3d_unet_desc* d, const float* x, const void* const* 
 
 }  // extern "C"
 
+// Exchange marks (data parallel): "record this event once every gradient of the segments <= seg is complete".  Set by
+// mi3d_unet_backward_marks for the NEXT backward call of the calling thread; that call stays ONE run of launches (a weight-gradient
+// slab sum of segment seg rides in the first BatchNorm-backward reduction of segment seg + 1, and the event is recorded right
+// behind that launch) instead of being cut into two calls at the exchange.
+struct BwdMarks { int n = 0; int seg[4]; hipEvent_t ev[4]; };
+static thread_local BwdMarks g_marks;
+extern "C" int mi3d_unet_backward_marks(const int* segs, void* const* events, int n) {
+    MI3D_CHECK_ARG(n >= 0 && n <= 4 && (n == 0 || (segs && events)), "mi3d_unet_backward_marks: at most 4 marks");
+    g_marks.n = n;
+    for (int i = 0; i < n; i++) { g_marks.seg[i] = segs[i]; g_marks.ev[i] = (hipEvent_t)events[i]; }
+    return 0;
+}
+extern "C" int mi3d_stream_wait_event(void* stream, void* event) {
+    MI3D_CHECK_ARG(event, "mi3d_stream_wait_event: null event");
+    MI3D_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return 0;
+}
+
 static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const void* const* params, void* const* grads,
                        const float* drop_scales, const float* dlogits_in, const float* dgap, float gap_scale, int accumulate,
                        int seg_begin, int seg_end, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream,
@@ -887,7 +907,17 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
     float* wgws = c.at<float>(p.wgws);
     c.defer_slabs = !mi3d_routes().no_pend_slabs;
     auto G = [&](int i) { return (float*)grads[i]; };
+    BwdMarks marks = g_marks;
+    g_marks.n = 0;
     for (int seg = seg_begin; seg < seg_end; seg++) {
+        if (seg > seg_begin)
+            for (int i = 0; i < marks.n; i++)
+                if (marks.seg[i] == seg - 1) {
+                    // two marks on one launch cannot happen (one event per segment); an older mark still pending means the
+                    // segment in between launched no BatchNorm backward: complete it now
+                    if (c.mark_pending) { MI3D_TRY(c.flush_pend()); MI3D_HIP(hipEventRecord(c.mark_pending, c.s)); }
+                    c.mark_pending = marks.ev[i];
+                }
         if (seg == 0) {
             if (!dlogits) continue;
             SlabJob* ps = c.pend_slot();
@@ -959,6 +989,9 @@ static int unet_backward_impl(const mi3d_unet_desc* d, const float* x, const voi
         }
     }
     MI3D_TRY(c.flush_pend());
+    if (c.mark_pending) { MI3D_HIP(hipEventRecord(c.mark_pending, c.s)); c.mark_pending = nullptr; }
+    for (int i = 0; i < marks.n; i++)
+        if (marks.seg[i] == seg_end - 1) MI3D_HIP(hipEventRecord(marks.ev[i], c.s));
     // weight gradients still queued (a call that ends before the group's own fork point): they go out now, so that every
     // gradient of the segments [seg_begin, seg_end) is at least in flight when the call returns
     if (c.s2 && c.ev) {

@@ -169,6 +169,8 @@ class _StepBase:
                                      fine_buckets=os.environ.get("MI3D_FINE_BUCKETS", "0") == "1")
         # the exchange stream must sit on another hardware queue than the compute stream (see concurrent_stream)
         self.comm_stream = concurrent_stream(self.device, role="comm") if self.do_comm else None
+        self._mark_handles = []          # exchange-mark events (mi3d_unet_backward_marks)
+        self._comm_flag, self._comm_seq = None, 0          # memory-flag join with the exchange stream (mi3d_flag_set / _wait)
         self.use_graph = bool(use_graph)
         self._statics = {}
         self._static = None
@@ -202,6 +204,9 @@ class _StepBase:
         self._closed = True
         try:
             self._drop_graphs()
+            for e in getattr(self, "_mark_handles", []):
+                _lib.lib().mi3d_event_destroy(e)
+            self._mark_handles = []
             self._close_extra()
         except Exception:      # noqa: BLE001  (interpreter shutdown: the library may already be gone)
             pass
@@ -570,6 +575,7 @@ class TrainStep(_StepBase):
         met = st["metrics"]
         met_pending = self.do_comm
         joined = False
+        join_fn = self._join_comm
         if run_backward:
             if not fused:
                 call("mi3d_seg_loss_backward", ptr(st["logits"]), ptr(st["y"]), ptr(t_logits), n, c, v, C.byref(self.cfg),
@@ -592,9 +598,23 @@ class TrainStep(_StepBase):
             # 256 - n CUs (the collective kernel holds the others: see mi3d_set_cu_budget)
             budget = int(os.environ.get("MI3D_COMM_CUS", "0")) if do_comm else 0
             in_flight = False
+            # exchange marks (include/mi3d.h, mi3d_unet_backward_marks): an eagerly launched step keeps the backward ONE call;
+            # the library records an event when a bucket's gradients are complete and the exchange stream waits for THAT
+            mid = [(sg, tuple(st["comm_after"][sg])) for sg in range(nseg - 1) if do_comm and st["comm_after"].get(sg)]
+            use_marks = bool(mid) and not self.use_graph and aux is None and not budget and len(mid) <= 4 and \
+                not os.environ.get("MI3D_NO_MARKS")
+            if use_marks:
+                while len(self._mark_handles) < len(mid):
+                    e = C.c_void_p()
+                    call("mi3d_event_create", C.byref(e))
+                    self._mark_handles.append(e.value)
+                call("mi3d_unet_backward_marks", (C.c_int * len(mid))(*[sg for sg, _ in mid]),
+                     ptr_table(self._mark_handles[:len(mid)]), len(mid))
             for seg in range(nseg):
                 last = seg == nseg - 1
                 exch = st["comm_after"].get(seg) if do_comm else None
+                if use_marks and not last:
+                    continue
                 if last or exch:
                     if budget and in_flight:
                         call("mi3d_set_cu_budget", budget)
@@ -616,6 +636,25 @@ class TrainStep(_StepBase):
                         call("mi3d_set_cu_budget", 0)
                     in_flight = in_flight or bool(exch)
                     start = seg + 1
+                    if use_marks:
+                        cs = self.comm_stream
+                        for i, (sg, b) in enumerate(mid):
+                            with_met, met_pending = met_pending, False
+                            call("mi3d_stream_wait_event", cs.cuda_stream, self._mark_handles[i])
+                            with torch.cuda.stream(cs):
+                                if with_met:
+                                    self.comm.average_(met)
+                                for k in b:
+                                    self.comm.reduce_bucket(k)
+                        if not os.environ.get("MI3D_NO_FLAG_JOIN"):
+                            # the compute stream's join with the exchange stream: a counter in memory the exchange stream bumps
+                            # behind its last collective and a one-wave poll on the compute stream (mi3d_flag_wait), instead of a
+                            # hardware cross-queue wait (30-45 us on the waiting stream even when the event fired long ago)
+                            if self._comm_flag is None:
+                                self._comm_flag = torch.zeros(2, dtype=torch.int64, device=self.device)
+                            self._comm_seq += 1
+                            call("mi3d_flag_set", ptr(self._comm_flag), self._comm_seq, cs.cuda_stream)
+                            join_fn = lambda q=self._comm_seq: call("mi3d_flag_wait", ptr(self._comm_flag), q, 2_000_000, stream_ptr())
                     if exch and not last:
                         with_met, met_pending = met_pending, False
                         comm(lambda b=tuple(exch), wm=with_met: self._on_comm_stream(
@@ -626,7 +665,7 @@ class TrainStep(_StepBase):
                         # other) -- one fork / join pair per step instead of two (a cross-queue dependency costs ~12 us)
                         with_met, met_pending = met_pending, False
                         joined = True
-                        comm(self._join_comm)
+                        comm(join_fn)
                         comm(lambda b=tuple(exch), wm=with_met: ([self.comm.average_(met)] if wm else []) +
                              [self.comm.reduce_bucket(k) for k in b])
             if aux_open:       # the last call may have had nothing for the aux stream: join what earlier calls left there
@@ -634,7 +673,7 @@ class TrainStep(_StepBase):
         if met_pending:
             comm(lambda: self._on_comm_stream(lambda: self.comm.average_(met)))
         if self.do_comm and not joined:
-            comm(self._join_comm)
+            comm(join_fn)
         if boundary and run_backward and self.aux_stream is not None and tail_k > 0:
             # AdamW over everything but the leading blocks + the re-pack of those weights for the next forward run on the aux
             # stream, behind the deferred weight gradients and beside the compute stream's last (full-resolution encoder) backward

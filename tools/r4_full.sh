@@ -1,0 +1,7 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -m pytest tests -m gpu -x -q > gpurun_out/r4_full_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r4_full_tests.log
+tail -8 gpurun_out/r4_full_tests.log
+bash tools/r4_shapes.sh > /dev/null 2>&1
+cat gpurun_out/r4_shapes.log
+cat gpurun_out/r4_shape_constants.log
