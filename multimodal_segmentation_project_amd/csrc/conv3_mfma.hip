@@ -1464,6 +1464,8 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     int ks = skws ? pick_ksplit(Cin, Cout, g, ks_target) : 1;
     if (ks > 1) MI3D_CHECK_ARG(ycs % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv3_mfma_fwd: split-K needs 16-B aligned output rows");
     if (big_geo(g)) {
+        // (round 4: ONE 16-channel output block per workgroup at the 16-wide levels -- twice the workgroups, half the chain each, the
+        // input tile staged twice -- measured slower: forward 98 -> 114 us/step, input gradients 80 -> 93; profiles/r04_experiments_misc.txt)
         if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s, false, relu);
         return launch_cfg<4, 8, 1, 16, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s, false, relu);
     }
