@@ -1733,8 +1733,12 @@ __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_persist_kernel(FusedPA
     extern __shared__ __attribute__((aligned(16))) char fusedp_lds[];
     int nw = a.wgx * a.wgy * a.wgz;
     int b = blockIdx.x;
-    // interleave the two kinds so that consecutive (same-CU) workgroup slots get one of each
-    bool is_w = (b & 1) == 0;           // even slots: weight gradient, odd slots: input gradient (surplus slots idle)
+    // The two kinds alternate over the block index: even = weight gradient, odd = input gradient.  Workgroup b is dispatched to
+    // XCD b % 8, so this puts ALL weight-gradient workgroups on XCDs 0,2,4,6 and all input-gradient workgroups on XCDs 1,3,5,7 --
+    // two of ONE kind per CU, each kind on half of the chip.  Round 4 measured the mapping rounds 2-3 believed they had (the kinds
+    // alternating INSIDE every XCD, one of each per CU, same tile sequence for both so that dy is fetched by one L2): 3 us per
+    // launch SLOWER (<1,1>: 68.3 vs 65.2 us, <1,2>: 25.5 vs 23.9; profiles/r04_experiments_misc.txt).  The split stays.
+    bool is_w = (b & 1) == 0;
     int idx = b >> 1;
     if (is_w) {
         if (idx >= nw) return;

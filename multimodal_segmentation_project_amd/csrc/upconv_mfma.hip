@@ -325,6 +325,7 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_weight_kernel(const bf16*
 struct UFusedArgs {
     const bf16* x; int xcs, Cin; const bf16* g; int gcs, Cout; const bf16* wb; bf16* dx; int dxcs; float* slabs;
     int N, D, H, W; int wgx, wgy, wgz, dgx, dgy;
+    int map;
 };
 template <int S, bool KSPLIT>
 __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_fused_kernel(UFusedArgs a) {
@@ -333,7 +334,14 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_bwd_fused_kernel(UFusedArgs a
     // one of each; the surplus of the longer list follows
     int b = blockIdx.x, m = nw < nd ? nw : nd;
     bool is_w; int idx;
-    if (b < 2 * m) { is_w = (b & 1) == 0; idx = b >> 1; }
+    const int m16 = (2 * m) & ~15;          // whole groups of 16 blocks: 8 XCDs x (one weight-gradient + one data-gradient block)
+    if (a.map && b < m16) {
+        // round 4: workgroup b runs on XCD b % 8, so "even = weight gradient, odd = data gradient" gave each XCD ONE kind; now the
+        // kinds alternate inside an XCD (its k-th block, k = b / 8, is a weight-gradient block iff k is even)
+        int xcd = b & 7, k = b >> 3;
+        is_w = (k & 1) == 0;
+        idx = (k >> 1) * 8 + xcd;
+    } else if (b < 2 * m) { is_w = (b & 1) == 0; idx = b >> 1; }
     else { is_w = nw > nd; idx = m + (b - 2 * m); }
     if (is_w) {
         b = idx;
@@ -449,7 +457,8 @@ int upconv2_mfma_bwd(const void* x, int xcs, int Cin, const void* gy, int gycs, 
         MI3D_CHECK_ARG(ws_floats >= (size_t)nsb * slab_sz, "upconv2_mfma_bwd: workspace too small");
         if (!ksp && gx * gy > dcap) gx = dcap / gy < 1 ? 1 : dcap / gy;          // persistent data-gradient workgroups
         UFusedArgs a{xp, xcs, Cin, gp, gycs, Cout, wb, (bf16*)dx, dxcs, ws, g.N, g.D, g.H, g.W,
-                     nsb, Cin / 32, (int)cdiv(Cout, 32), ksp ? (int)gkx : gx, ksp ? Cin / 16 : gy};
+                     nsb, Cin / 32, (int)cdiv(Cout, 32), ksp ? (int)gkx : gx, ksp ? Cin / 16 : gy,
+                     mi3d_routes().no_upbwd_xcd_mix ? 0 : 1};
         size_t lds = (size_t)(2 * UV + 16 * UV) * 32;
         unsigned nblk = (unsigned)(a.wgx * a.wgy * a.wgz + a.dgx * a.dgy);
 #define UFL(SS, KS_)                                                                                                          \
