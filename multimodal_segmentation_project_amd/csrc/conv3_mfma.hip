@@ -1530,7 +1530,10 @@ template <int CO_B, int CI_B, int NT>
 __device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restrict__ x, int xcs, int Cin,
                                                  const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
                                                  int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
-                                                 float* __restrict__ slabs, Halves xh) {
+                                                 float* __restrict__ slabs, Halves xh, int xcd_tiles = 0) {
+    // xcd_tiles (full-resolution layers, round 4): slab workgroups b, b + 8, ... run on one XCD (round-robin dispatch) and take
+    // ADJACENT tiles (xcd_contig), so that the x-halo voxels neighbouring tiles share are served by that XCD's L2.  Before, tile =
+    // slab index put neighbouring tiles on neighbouring XCDs and every halo was fetched twice (decoder.3.conv0: 261 MB for 170 MB)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16* dys = reinterpret_cast<bf16*>(lds_raw);                 // [CO_B][WNV][16]
     bf16* xs = dys + CO_B * WNV * 16;                             // [CI_B][WNH][16]
@@ -1613,8 +1616,9 @@ __device__ __forceinline__ void conv3_wgrad_body(Bid bid_, const bf16* __restric
     };
     // prefetch the next tile into registers while computing (only where the register file has room for it)
     constexpr bool PF = (NT * CO_B * CI_B + NA + NB) * 4 <= 300;
-    if (PF && sb < ntiles) load_tile(sb);
-    for (int tile = sb; tile < ntiles; tile += nsb) {
+    const int tile0 = xcd_tiles ? xcd_contig(sb, nsb) : sb;
+    if (PF && tile0 < ntiles) load_tile(tile0);
+    for (int tile = tile0; tile < ntiles; tile += nsb) {
         if (!PF) load_tile(tile);
         __syncthreads();
 #pragma unroll
@@ -1706,8 +1710,19 @@ template <int CO_B, int CI_B, int NT>
 __global__ __launch_bounds__(BLK, (NT * CO_B * CI_B <= 27) ? 2 : 1) void conv3_wgrad_mfma_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                                const bf16* __restrict__ dy, int dycs, int Cout, int N, int D,
                                                                int H, int W, int tilesZ, int tilesY, int tilesX, int TG,
-                                                               float* __restrict__ slabs, Halves xh) {
-    conv3_wgrad_body<CO_B, CI_B, NT>(real_bid(), x, xcs, Cin, dy, dycs, Cout, N, D, H, W, tilesZ, tilesY, tilesX, TG, slabs, xh);
+                                                               float* __restrict__ slabs, Halves xh, int xcd_tiles,
+                                                               int pgx, int pgy, int pgz) {
+    // pgx > 0: flat 1-D grid of pgx * pgy * pgz workgroups, PLACED like the weight-gradient half of the fused launch -- the
+    // (co, ci)-block workgroups of one slab (they re-read the same dy / x tiles) and neighbouring slabs sit on one XCD (round 4:
+    // the stand-alone kernel carries every deferred weight gradient of the aux-stream route; with the natural 3-D grid the
+    // blocks of one slab were spread over all eight L2s)
+    if (pgx > 0) {
+        int f = xcd_contig((int)blockIdx.x, pgx * pgy * pgz), G = pgy * pgz, yz = f % G;
+        conv3_wgrad_body<CO_B, CI_B, NT>(Bid{f / G, yz % pgy, yz / pgy, pgx, pgy, pgz}, x, xcs, Cin, dy, dycs, Cout, N, D, H, W, tilesZ, tilesY,
+                                         tilesX, TG, slabs, xh, 0);
+        return;
+    }
+    conv3_wgrad_body<CO_B, CI_B, NT>(real_bid(), x, xcs, Cin, dy, dycs, Cout, N, D, H, W, tilesZ, tilesY, tilesX, TG, slabs, xh, xcd_tiles);
 }
 
 // Horizontal fusion for the deep levels: workgroups [0, nwg_w) run the weight gradient of a layer, the rest its
@@ -1727,6 +1742,7 @@ struct FusedPArgs {
     const bf16* wx; int wxcs, wCin; const bf16* wdy; int wdycs, wCout; int tZ, tY, tX; float* slabs; int wgx, wgy, wgz; Halves wxh;
     const bf16* dxin; int dxcs_in; const bf16* dwp; bf16* dyout; int dycs_out; int ptZ, ptY, ptX, pnt, pgrid; Halves dyh;
     int N, D, H, W;
+    int xcd_tiles;
 };
 template <int COB, int NCH>
 __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_persist_kernel(FusedPArgs a) {
@@ -1743,7 +1759,8 @@ __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_persist_kernel(FusedPA
     if (is_w) {
         if (idx >= nw) return;
         Bid v{idx % a.wgx, (idx / a.wgx) % a.wgy, idx / (a.wgx * a.wgy), a.wgx, a.wgy, a.wgz};
-        conv3_wgrad_body<1, 1, 27>(v, a.wx, a.wxcs, a.wCin, a.wdy, a.wdycs, a.wCout, a.N, a.D, a.H, a.W, a.tZ, a.tY, a.tX, 1, a.slabs, a.wxh);
+        conv3_wgrad_body<1, 1, 27>(v, a.wx, a.wxcs, a.wCin, a.wdy, a.wdycs, a.wCout, a.N, a.D, a.H, a.W, a.tZ, a.tY, a.tX, 1, a.slabs, a.wxh,
+                                   a.xcd_tiles);
     } else {
         if (idx >= a.pgrid) return;
         Bid v{idx, 0, 0, a.pgrid, 1, 1};
@@ -2111,13 +2128,24 @@ int launch_wgrad(const bf16* x, int xcs, int Cin, const bf16* dy, int dycs, int 
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
     MI3D_SET_MAX_LDS_ONCE((&conv3_wgrad_mfma_kernel<CO_B, CI_B, NT>), lds);
     dim3 grid((unsigned)(c.nsb * c.tg), (unsigned)(Cout / (16 * CO_B)), (unsigned)(Cin / (16 * CI_B)));
+    // full-resolution layers: the XCD-aware tile assignment of the fused launch (the stand-alone kernel must sum the same tiles into
+    // the same slabs: both routes produce the same bits)
+    const bool full = persist_ok(Cout, Cin, g);
+    const int xcd_tiles = (full && !mi3d_routes().no_wgrad_xcd) ? 1 : 0;
+    // every other layer: flat, placed grid (see the kernel); same slabs, same tiles per slab, same bits
+    int pgx = 0, pgy = 0, pgz = 0;
+    if (!full && c.tg == 1 && !mi3d_routes().no_wgrad_xcd) {
+        pgx = (int)grid.x; pgy = (int)grid.y; pgz = (int)grid.z;
+        grid = dim3((unsigned)(pgx * pgy * pgz));
+    }
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
     if (time_hook_take(1, Cin, Cout, tev0, tev1))
         hipExtLaunchKernelGGL((conv3_wgrad_mfma_kernel<CO_B, CI_B, NT>), grid, dim3(BLK), lds, s, tev0, tev1, 0, x, xcs, Cin, dy, dycs, Cout,
-                              g.N, g.D, g.H, g.W, cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh);
+                              g.N, g.D, g.H, g.W, cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh, xcd_tiles, pgx, pgy, pgz);
     else
         conv3_wgrad_mfma_kernel<CO_B, CI_B, NT><<<grid, BLK, lds, s>>>(x, xcs, Cin, dy, dycs, Cout, g.N, g.D, g.H, g.W,
-                                                                      cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh);
+                                                                      cdiv(g.D, WTZ), cdiv(g.H, WTY), cdiv(g.W, WTX), c.tg, slabs, xh, xcd_tiles,
+                                                                      pgx, pgy, pgz);
     MI3D_LAUNCH_CHECK();
     return 0;
 }
@@ -2211,6 +2239,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     a.ptZ = cdiv(g.D, 4); a.ptY = cdiv(g.H, 8); a.ptX = cdiv(g.W, 16); a.pnt = g.N * a.ptZ * a.ptY * a.ptX;
     a.pgrid = a.pnt < pcap ? a.pnt : pcap; a.dyh = dxh;
     a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
+    a.xcd_tiles = mi3d_routes().no_wgrad_xcd ? 0 : 1;
     int nw = a.wgx * a.wgy * a.wgz;
     int half = nw > a.pgrid ? nw : a.pgrid;
     unsigned nblk = (unsigned)(2 * half);
