@@ -301,13 +301,18 @@ __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, 
 // Second half of an encoder block: the same apply pass, one thread per 2x2x2 pooling window and channel group — writes the
 // eight activated voxels (the skip tensor) AND their maximum (MaxPool3d(2,2), models/unet.py:40,71), so the pooling launch and
 // its re-read of the skip tensor disappear.  Even D, H, W only (every voxel lies in exactly one window).
-template <typename T, int VEC, bool TRAIN>
+// PAIR (round 4, VEC = 8, C / 8 a power of two <= 32): two threads per window -- thread (window, c, g) owns the four voxels (a, b, c),
+// so the lanes of a wave touch one contiguous run per (a, b) instead of every other 32-B half; the halves exchange their maxima with
+// one lane swap (the maximum of the same eight stored values: bit-identical)
+template <typename T, int VEC, bool TRAIN, bool PAIR = false>
 __global__ __launch_bounds__(BLK) void bn_apply_pool_kernel(const T* __restrict__ y, int ycs, int C, int N, int D, int H, int W,
                                                             float* __restrict__ stat, BnPart tr, const float* __restrict__ drop,
                                                             T* __restrict__ z, int zcs, T* __restrict__ pl, int pcs) {
     const int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
     const unsigned gtid = blockIdx.x * BLK + threadIdx.x;
     const int g = (int)(gtid % (unsigned)G);
+    [[maybe_unused]] const int pc = PAIR ? (int)((gtid / (unsigned)G) & 1u) : 0;
+    constexpr int NK = PAIR ? 4 : 8;
     float a[VEC], b[VEC];
     if constexpr (TRAIN) {
         __shared__ double red[BLK * 4];
@@ -319,12 +324,13 @@ __global__ __launch_bounds__(BLK) void bn_apply_pool_kernel(const T* __restrict_
 #pragma unroll
         for (int i = 0; i < VEC; i++) { a[i] = stat[2 * C + g * VEC + i]; b[i] = stat[3 * C + g * VEC + i]; }
     }
-    const unsigned windows = (unsigned)N * Do * Ho * Wo, wstep = (gridDim.x * BLK) / (unsigned)G;
+    const unsigned TPW = (unsigned)G * (PAIR ? 2u : 1u);          // threads per window
+    const unsigned windows = (unsigned)N * Do * Ho * Wo, wstep = (gridDim.x * BLK) / TPW;
     float ds[VEC];
     int dn = -1;
 #pragma unroll
     for (int i = 0; i < VEC; i++) ds[i] = 1.f;
-    for (unsigned win = gtid / (unsigned)G; win < windows; win += wstep) {
+    for (unsigned win = gtid / TPW; win < windows; win += wstep) {
         unsigned r = win;
         const int wo = (int)(r % (unsigned)Wo); r /= (unsigned)Wo;
         const int ho = (int)(r % (unsigned)Ho); r /= (unsigned)Ho;
@@ -335,26 +341,33 @@ __global__ __launch_bounds__(BLK) void bn_apply_pool_kernel(const T* __restrict_
 #pragma unroll
             for (int i = 0; i < VEC; i++) ds[i] = drop[(int64_t)n * C + g * VEC + i];
         }
-        float v[8][VEC], m[VEC];
+        float v[NK][VEC], m[VEC];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int q = 0; q < NK; q++) {
+            const int k = PAIR ? 2 * q + pc : q;
             const int64_t off = (((int64_t)n * D + 2 * d_o + (k >> 2)) * H + 2 * ho + ((k >> 1) & 1)) * W + 2 * wo + (k & 1);
-            ldv<T, VEC>(y + off * ycs + g * VEC, v[k]);
+            ldv<T, VEC>(y + off * ycs + g * VEC, v[q]);
         }
 #pragma unroll
         for (int i = 0; i < VEC; i++) m[i] = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int q = 0; q < NK; q++) {
+            const int k = PAIR ? 2 * q + pc : q;
             const int64_t off = (((int64_t)n * D + 2 * d_o + (k >> 2)) * H + 2 * ho + ((k >> 1) & 1)) * W + 2 * wo + (k & 1);
             float o[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
-                float t = fmaf(v[k][i], a[i], b[i]);
+                float t = fmaf(v[q][i], a[i], b[i]);
                 t = t > 0.f ? t : 0.f;
                 o[i] = (float)(T)(t * ds[i]);             // the pooled value is the maximum of the STORED (rounded) values
                 m[i] = o[i] > m[i] ? o[i] : m[i];
             }
             stv<T, VEC>(z + off * zcs + g * VEC, o);
+        }
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int i = 0; i < VEC; i++) { float om = __shfl_xor(m[i], G, 64); m[i] = om > m[i] ? om : m[i]; }
+            if (pc != 0) continue;
         }
         stv<T, VEC>(pl + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * pcs + g * VEC, m);
     }
@@ -666,7 +679,12 @@ int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, flo
         bool v8 = vec8_ok(C, ycs, zcs, y, z, sizeof(T)) && pcs % 8 == 0 && ((uintptr_t)pooled % 16 == 0);
         int grid = v8 ? stream_grid(M / 8 * (C / 8), C / 8) : stream_grid(M / 8 * C, C);
         const T* yp = (const T*)y; T* zp = (T*)z; T* pp = (T*)pooled;
-        if (v8 && small) bn_apply_pool_kernel<T, 8, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
+        const int G8 = C / 8;
+        const bool pair = v8 && (G8 & (G8 - 1)) == 0 && G8 <= 32 && !mi3d_routes().no_pool_pair;
+        if (pair) grid = stream_grid(M / 8 * G8 * 2, G8 * 2);
+        if (pair && small) bn_apply_pool_kernel<T, 8, true, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
+        else if (pair) bn_apply_pool_kernel<T, 8, false, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
+        else if (v8 && small) bn_apply_pool_kernel<T, 8, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
         else if (v8) bn_apply_pool_kernel<T, 8, false><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
         else if (small) bn_apply_pool_kernel<T, 1, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
         else bn_apply_pool_kernel<T, 1, false><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);

@@ -72,6 +72,7 @@ void mi3d_set_error(const char* fmt, ...);
     X(aux_wg_target, 0)     /* workgroups of a weight gradient on the aux stream (0: the fused launch's partition) */ \
     X(apply_on_load, 0)     /* MI3D_EXPERIMENTS builds only (round 4, measured slower): deep levels apply BatchNorm in the next conv's staging pass instead of a bn_apply / bn_bwd_apply launch */ \
     X(no_pool_splitk, 0)    /* 1: a split-K gradient of a pooled tensor is finished by its own pass, not inside the MaxPool3d backward */ \
+    X(no_pool_pair, 0)      /* 1: MaxPool3d backward with one thread per window (rounds 1-3) instead of two */ \
     X(no_wgrad_xcd, 0)      /* 1: full-resolution weight gradients take tile = slab index (rounds 1-3) instead of XCD-contiguous tiles */ \
     X(no_upbwd_xcd_mix, 0)  /* 1: fused transposed-conv backward with the round-3 block mapping (even blocks weight gradient, odd data gradient: one kind per XCD) */ \
     X(g1_fork_late, 0)      /* 1: the decoder's full-resolution weight gradients fork when the chain enters the deep levels */ \

@@ -92,6 +92,75 @@ __global__ __launch_bounds__(BLK) void maxpool2_bwd_kernel(const T* __restrict__
     }
 }
 
+// The same pass with TWO threads per window and channel group (round 4): thread (window, c, g) owns the four voxels (a, b, c) of
+// the window, so for every (a, b) the lanes of a wave read / write one contiguous run of memory (lane stride 16 B) instead of every
+// other 32-B half of it (the one-thread-per-window kernel: 41 us = 4.3 TB/s at full resolution).  The two halves of a window combine
+// their (maximum, first index) through one lane exchange; ties and non-finite values resolve exactly like the sequential strict `>`
+// scan over k = 4a + 2b + c (first occurrence of the maximum; index 0 when nothing exceeds -inf).  G = C / 8 a power of two <= 32.
+template <typename T>
+__global__ __launch_bounds__(BLK) void maxpool2_bwd_pair_kernel(const T* __restrict__ dp, int dpcs, const T* __restrict__ z, int zcs,
+                                                                const T* __restrict__ dskip, int dskipcs, T* __restrict__ dz,
+                                                                int dzcs, int C, int N, int D, int H, int W,
+                                                                const float* __restrict__ skp, int ks) {
+    constexpr int VEC = 8;
+    int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+    int64_t total = (int64_t)N * Do * Ho * Wo * G * 2;
+    for (int64_t idx = (int64_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLK) {
+        unsigned iu = (unsigned)idx, r = iu / (unsigned)G;
+        int g = (int)(iu - r * (unsigned)G);
+        int c = (int)(r & 1u); r >>= 1;
+        int wo = (int)(r % (unsigned)Wo); r /= (unsigned)Wo; int ho = (int)(r % (unsigned)Ho); r /= (unsigned)Ho;
+        int d_o = (int)(r % (unsigned)Do); int n = (int)(r / (unsigned)Do);
+        float v[4][VEC], m[VEC], gp[VEC];
+        int arg[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; i++) { m[i] = -INFINITY; arg[i] = 99; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int a = q >> 1, b = q & 1, k = 4 * a + 2 * b + c;
+            ldv<T, VEC>(z + ((((int64_t)n * D + 2 * d_o + a) * H + 2 * ho + b) * W + 2 * wo + c) * zcs + g * VEC, v[q]);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) if (v[q][i] > m[i]) { m[i] = v[q][i]; arg[i] = k; }
+        }
+        // the other half of the window: lane ^ G (G <= 32: same wave; both halves of a window are always active together)
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            float om = __shfl_xor(m[i], G, 64);
+            int oa = __shfl_xor(arg[i], G, 64);
+            bool take = (oa != 99) && (arg[i] == 99 || om > m[i] || (om == m[i] && oa < arg[i]));
+            arg[i] = take ? oa : arg[i];
+            if (arg[i] == 99) arg[i] = 0;
+        }
+        if (skp) {
+            const int64_t row = (((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo, Mp = (int64_t)N * Do * Ho * Wo;
+#pragma unroll
+            for (int i = 0; i < VEC; i++) gp[i] = 0.f;
+            for (int k = 0; k < ks; k++) {
+                const float* pp = skp + ((int64_t)k * Mp + row) * C + g * VEC;
+#pragma unroll
+                for (int i = 0; i < VEC; i++) gp[i] += pp[i];
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; i++) gp[i] = round_to<T>(gp[i]);
+        } else
+            ldv<T, VEC>(dp + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * dpcs + g * VEC, gp);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int a = q >> 1, b = q & 1, k = 4 * a + 2 * b + c;
+            int64_t off = (((int64_t)n * D + 2 * d_o + a) * H + 2 * ho + b) * W + 2 * wo + c;
+            float o[VEC];
+            if (dskip) ldv<T, VEC>(dskip + off * dskipcs + g * VEC, o);
+            else {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) o[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; i++) o[i] += (arg[i] == k) ? gp[i] : 0.f;
+            stv<T, VEC>(dz + off * dzcs + g * VEC, o);
+        }
+    }
+}
+
 // odd D/H/W: MaxPool3d floors (the last slice of an odd dimension is in no window) -> those voxels only receive the
 // skip gradient
 template <typename T>
@@ -181,7 +250,10 @@ int maxpool2_bwd(int dtype, const void* dp, int dpcs, const void* z, int zcs, co
     DISPATCH_T(dtype, T, {
         bool v8 = C % 8 == 0 && zcs % 8 == 0 && dpcs % 8 == 0 && dzcs % 8 == 0 && (!dskip || dskipcs % 8 == 0) &&
                   al16(z) && al16(dp) && al16(dz) && al16(dskip);
-        if (v8)
+        const int G8 = C / 8;
+        if (v8 && (G8 & (G8 - 1)) == 0 && G8 <= 32 && nout * G8 * 2 < (1ll << 31) && !mi3d_routes().no_pool_pair)
+            maxpool2_bwd_pair_kernel<T><<<sgrid(nout * G8 * 2), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W, skp, ks);
+        else if (v8)
             maxpool2_bwd_kernel<T, 8><<<sgrid(nout * (C / 8)), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W, skp, ks);
         else
             maxpool2_bwd_kernel<T, 1><<<sgrid(nout * C), BLK, 0, s>>>((const T*)dp, dpcs, (const T*)z, zcs, (const T*)dskip, dskipcs, (T*)dz, dzcs, C, g.N, g.D, g.H, g.W, skp, ks);

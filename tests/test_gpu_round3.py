@@ -261,6 +261,13 @@ def test_round2_routes_are_invisible_at_the_headline_shape(routes, golden):
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
     routes.reset("no_pool_splitk")
+    # round 4: MaxPool3d backward with two threads per window (same first-maximum routing, same sums)
+    routes.set("no_pool_pair", 1)
+    l1, o1, g1 = run()
+    assert l1 == l0 and torch.equal(o1, o0)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    routes.reset("no_pool_pair")
     for sw in ("no_fused_bwd_big", "no_fused_bwd_p"):
         routes.set(sw, 1)
         l2, o2, g2 = run()
