@@ -69,17 +69,13 @@ void mi3d_set_error(const char* fmt, ...);
     X(fused_wg_target, 288) /* weight-gradient workgroups of a fused deep-level backward launch */                  \
     X(no_defer_wgrad, 0)    /* round 4: weight gradients stay on the data-gradient chain even with an aux stream */ \
     X(defer_mask, 7)        /* which weight gradients go to the aux stream: 1 decoder level 0, 2 decoder level 1, 4 deep levels */ \
-    X(aux_wg_target, 0)     /* workgroups of a weight gradient on the aux stream (0: the fused launch's partition) */ \
     X(apply_on_load, 0)     /* MI3D_EXPERIMENTS builds only (round 4, measured slower): deep levels apply BatchNorm in the next conv's staging pass instead of a bn_apply / bn_bwd_apply launch */ \
     X(no_pool_splitk, 0)    /* 1: a split-K gradient of a pooled tensor is finished by its own pass, not inside the MaxPool3d backward */ \
+    X(no_wide_store, 0)     /* 1: persistent conv epilogue with two 8-byte stores per lane and row pair instead of one 16-byte store */ \
     X(no_pool_pair, 0)      /* 1: MaxPool3d backward with one thread per window (rounds 1-3) instead of two */ \
     X(no_wgrad_xcd, 0)      /* 1: full-resolution weight gradients take tile = slab index (rounds 1-3) instead of XCD-contiguous tiles */ \
     X(no_upbwd_xcd_mix, 0)  /* 1: fused transposed-conv backward with the round-3 block mapping (even blocks weight gradient, odd data gradient: one kind per XCD) */ \
-    X(g1_fork_late, 0)      /* 1: the decoder's full-resolution weight gradients fork when the chain enters the deep levels */ \
     X(opt_tail, 0)          /* 1: AdamW + weight re-pack of everything but the leading encoder blocks on the aux stream beside the end of the backward (TrainStep reads it; measured neutral: the aux stream is the long pole there) */ \
-    X(no_lazy_aux, 0)       /* 1: the deep-level weight gradients are enqueued on the aux stream all at once at their fork */ \
-    X(aux_drain, 3)         /* forked weight gradients the host enqueues on the aux stream per conv layer of the chain */ \
-    X(defer_fork_each, 0)   /* 1: every deferred weight gradient goes to the aux stream as soon as its dy exists (one event record per layer; the chain still never waits) */ \
     X(conv_dma, 0)          /* MI3D_EXPERIMENTS builds only: LDS-DMA staging in the Cout = 16 persistent forward conv */
 struct Mi3dRoutes {
 #define MI3D_ROUTE_FIELD(name, dflt) int name = dflt;

@@ -918,6 +918,39 @@ __device__ __forceinline__ void conv3_mfma_persist_body(Bid bid_, const bf16* __
         int gz = z0 + wave, gx = x0 + vn;
         bf16* yrow = y + ((((int64_t)n * D + gz) * H + y0) * W + gx) * ycs + g * 4;
         bool okzx = gz < D && gx < W;
+        if (relu & 2) {
+            // wide stores (round 4): a lane holds 4 channels (8 B) of one voxel per M-block row; rows r and r + 1 trade halves through
+            // v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second), after which lane (vn, g) holds 8
+            // consecutive channels (g >> 1) * 8 .. + 7 of voxel vn in row r + (g & 1): ONE 16-B store instead of two 8-B ones
+            bf16* ywide = y + ((((int64_t)n * D + gz) * H + y0 + (g & 1)) * W + gx) * ycs + (g >> 1) * 8;
+#pragma unroll
+            for (int r = 0; r < MB; r += 2) {
+                const bool okw = okzx && (y0 + r + (g & 1)) < H;
+#pragma unroll
+                for (int c = 0; c < COB; c++) {
+                    bf16x4 oa, ob;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float va = acc[r][c][j] + bv[c][j], vb = acc[r + 1][c][j] + bv[c][j];
+                        if (relu & 1) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+                        oa[j] = (bf16)va; ob[j] = (bf16)vb;
+                        if (STATS) {
+                            float qa = (okzx && (y0 + r) < H) ? (float)oa[j] : 0.f, qb = (okzx && (y0 + r + 1) < H) ? (float)ob[j] : 0.f;
+                            s1[c][j] += qa; s2[c][j] = fmaf(qa, qa, s2[c][j]);
+                            s1[c][j] += qb; s2[c][j] = fmaf(qb, qb, s2[c][j]);
+                        }
+                    }
+                    typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+                    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+                    u32x2 ua = __builtin_bit_cast(u32x2, oa), ub = __builtin_bit_cast(u32x2, ob);
+                    u32x2 s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
+                    u32x2 s1_ = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
+                    u32x4 w = {s0[0], s1_[0], s0[1], s1_[1]};
+                    if (okw) *reinterpret_cast<u32x4*>(ywide + (int64_t)r * W * ycs + c * 16 + (c >= yh.split ? yh.delta : 0)) = w;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < MB; r++) {
             bool ok = okzx && (y0 + r) < H;
@@ -1423,6 +1456,8 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     bool two = Cout % 32 == 0;
     if (persist_ok(Cin, Cout, g)) {
         int tz = cdiv(g.D, 4), ty = cdiv(g.H, 8), tx = cdiv(g.W, 16), nt = g.N * tz * ty * tx, grid = persist_grid(Cin, Cout, g);
+        // bit 1 of the relu word: 16-byte epilogue stores (two M-block rows trade halves through v_permlane16_swap)
+        if (!mi3d_routes().no_wide_store && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0 && yh.delta % 8 == 0) relu |= 2;
 #define PK(COB_, NCH_)                                                                                                         \
         do {                                                                                                                   \
             hipEvent_t tev0 = nullptr, tev1 = nullptr;                                                                          \
@@ -1444,9 +1479,9 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
 #define PD(NCH_)                                                                                                              \
             do {                                                                                                              \
                 if (part) { MI3D_SET_MAX_LDS_ONCE((&conv3_mfma_persist_dma_kernel<NCH_, true>), lds);                         \
-                    conv3_mfma_persist_dma_kernel<NCH_, true><<<grid, BLK, lds, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu); } \
+                    conv3_mfma_persist_dma_kernel<NCH_, true><<<grid, BLK, lds, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, part, xh, yh, relu & 1); } \
                 else { MI3D_SET_MAX_LDS_ONCE((&conv3_mfma_persist_dma_kernel<NCH_, false>), lds);                             \
-                    conv3_mfma_persist_dma_kernel<NCH_, false><<<grid, BLK, lds, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh, relu); } \
+                    conv3_mfma_persist_dma_kernel<NCH_, false><<<grid, BLK, lds, s>>>(xp, xcs, w, bias, yp, ycs, g.D, g.H, g.W, tz, ty, tx, nt, nullptr, xh, yh, relu & 1); } \
             } while (0)
             if (Cin == 16) PD(1); else PD(2);
 #undef PD
@@ -1742,7 +1777,7 @@ struct FusedPArgs {
     const bf16* wx; int wxcs, wCin; const bf16* wdy; int wdycs, wCout; int tZ, tY, tX; float* slabs; int wgx, wgy, wgz; Halves wxh;
     const bf16* dxin; int dxcs_in; const bf16* dwp; bf16* dyout; int dycs_out; int ptZ, ptY, ptX, pnt, pgrid; Halves dyh;
     int N, D, H, W;
-    int xcd_tiles;
+    int xcd_tiles, flags;
 };
 template <int COB, int NCH>
 __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_persist_kernel(FusedPArgs a) {
@@ -1765,7 +1800,7 @@ __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_persist_kernel(FusedPA
         if (idx >= a.pgrid) return;
         Bid v{idx, 0, 0, a.pgrid, 1, 1};
         conv3_mfma_persist_body<COB, NCH, false, true>(v, a.dxin, a.dxcs_in, a.dwp, nullptr, a.dyout, a.dycs_out, a.D, a.H, a.W, a.ptZ, a.ptY,
-                                                       a.ptX, a.pnt, nullptr, Halves(), a.dyh, fusedp_lds);
+                                                       a.ptX, a.pnt, nullptr, Halves(), a.dyh, fusedp_lds, a.flags);
     }
 }
 
@@ -2240,6 +2275,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     a.pgrid = a.pnt < pcap ? a.pnt : pcap; a.dyh = dxh;
     a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
     a.xcd_tiles = mi3d_routes().no_wgrad_xcd ? 0 : 1;
+    a.flags = (!mi3d_routes().no_wide_store && dxcs % 8 == 0 && ((uintptr_t)dx % 16) == 0 && dxh.delta % 8 == 0) ? 2 : 0;
     int nw = a.wgx * a.wgy * a.wgz;
     int half = nw > a.pgrid ? nw : a.pgrid;
     unsigned nblk = (unsigned)(2 * half);

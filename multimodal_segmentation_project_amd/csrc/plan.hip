@@ -398,7 +398,7 @@ int drain_aux(const Ctx& c, const float* x, void* const* grads, int accumulate, 
 // buffers are complete).  lazy: only the event is recorded here, the launches are enqueued by later drain_aux calls.
 int flush_deferred(const Ctx& c, const float* x, void* const* grads, int accumulate, bool lazy = false, bool force = false) {
     if (c.ndq == 0 && force) {
-        if (c.nfork >= 3) MI3D_TRY(drain_aux(c, x, grads, accumulate, -1));      // (event reuse: everything forked earlier is enqueued first)
+        MI3D_CHECK_ARG(c.nfork < 3, "flush_deferred: more than three forks in one call");
         // nothing queued (defer_mask), but the caller relies on the aux stream being ordered after this point of the chain
         // (mi3d_unet_chain_tail_blocks: its optimizer tail runs there)
         const int e = c.nfork++;
@@ -409,10 +409,7 @@ int flush_deferred(const Ctx& c, const float* x, void* const* grads, int accumul
         return 0;
     }
     if (c.ndq == 0) return 0;
-    MI3D_CHECK_ARG(c.nfork < 3 || mi3d_routes().defer_fork_each, "flush_deferred: more than three forks in one call");
-    // (fork_each: the three fork events are re-recorded in turn; a stream wait keeps the record it was issued after -- so
-    // everything forked earlier is enqueued first)
-    if (c.nfork >= 3) MI3D_TRY(drain_aux(c, x, grads, accumulate, -1));
+    MI3D_CHECK_ARG(c.nfork < 3, "flush_deferred: more than three forks in one call");
     const int e = c.nfork++;
     MI3D_HIP(hipEventRecord(c.ev[e % 3], c.s));
     for (int q = 0; q < c.ndq; q++) c.hq[c.nhq++] = Ctx::HJob{c.dq[q].b, c.dq[q].h, c.dq[q].wg_target, e};
@@ -436,10 +433,7 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
     for (int h = 1; h >= 0; h--) {
         const HalfP& H = B.h[h];
         int k = c.seq++;
-        if (aux && c.nhq) MI3D_TRY(drain_aux(c, x, grads, accumulate, mi3d_routes().aux_drain));      // feed the aux stream between the chain's launches
-        // g1_fork_late: the decoder's full-resolution weight gradients start when the chain ENTERS the deep levels (first launch of
-        // the block below the last 16-wide decoder block), not beside that block's own input-gradient conv and transposed conv
-        if (aux && mi3d_routes().g1_fork_late && h == 1 && b == p.flush_b[0] - 1) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
+        if (aux && c.nhq) MI3D_TRY(drain_aux(c, x, grads, accumulate, 3));      // feed the aux stream between the chain's launches
         // deferred weight gradient: dy goes to the layer's own buffer, which nobody overwrites before the aux stream has read it
         const int dbit = H.defer == 2 ? 4 : (B.level == 0 ? 1 : 2);
         const bool dfr = aux && H.defer && (mi3d_routes().defer_mask & dbit) && (G(H.pidx) || G(H.pidx + 1));
@@ -466,23 +460,19 @@ int block_backward(const Ctx& c, int b, const float* x, void* const* grads, cons
             // the chain runs the input-gradient conv alone; the weight gradient is queued for the aux stream.  Its slab partition
             // is the fused launch's (conv3_mfma_bwd_wg_target), the input gradient uses the fused launch's split-K factor and the
             // same K order: both routes produce the same bits
-            const int awt = mi3d_routes().aux_wg_target;
-            c.dq[c.ndq++] = Ctx::DJob{b, h, awt > 0 ? awt : conv3_mfma_bwd_wg_target(H.Cin, H.Cout, ics, H.Cout, dx_f ? dxs_f : 8, g)};
+            c.dq[c.ndq++] = Ctx::DJob{b, h, conv3_mfma_bwd_wg_target(H.Cin, H.Cout, ics, H.Cout, dx_f ? dxs_f : 8, g)};
         }
         // fork points: what is queued goes to the aux stream when the chain has finished the last layer of a group -- its
         // BatchNorm backward, or (apply on load) the input-gradient conv that writes dy -- whether or not that very layer is
         // deferred under the current defer_mask
         auto fork_here = [&]() -> int {
             if (!aux) return 0;
-            // defer_fork_each = 1: every deferred layer forks on its own; = 2: only the deep-level layers do (the aux stream is
-            // idle between the end of the decoder's full-resolution weight gradients and the fork behind the deep chain)
-            const int fe = mi3d_routes().defer_fork_each;
-            if (fe == 1 || (fe == 2 && H.defer == 2 && dfr)) MI3D_TRY(flush_deferred(c, x, grads, accumulate));
             // group 1 forks when the GPU is still busy with the full-resolution decoder (the host is far ahead: enqueue at once);
-            // group 2 forks at the end of the launch-bound deep chain: its launches are fed in between the chain's next ones
+            // group 2 forks at the end of the launch-bound deep chain: its launches are fed in between the chain's next ones.
+            // (Measured and dropped, profiles/r04_experiments_aux_wgrad.txt / _opt_tail_pool_forks.txt: one fork per layer +26 ... +43 us,
+            // per deep layer only +6 us, the decoder fork one block later -1 us, another workgroup count for the aux kernels +10 ... +40 us)
             for (int q = 0; q < 2; q++)
-                if (b == p.flush_b[q] && h == p.flush_h[q] && !(q == 0 && mi3d_routes().g1_fork_late))
-                    MI3D_TRY(flush_deferred(c, x, grads, accumulate, q == 1 && !mi3d_routes().no_lazy_aux, q == 1));
+                if (b == p.flush_b[q] && h == p.flush_h[q]) MI3D_TRY(flush_deferred(c, x, grads, accumulate, q == 1, q == 1));
             return 0;
         };
         if (xf_rows == 0) MI3D_TRY(fork_here());
