@@ -661,18 +661,37 @@ __global__ __launch_bounds__(512, XF == 2 ? 2 : 4) void conv3_mfma8_kernel(const
         int gz = z0 + zs, gy = y0 + byb * BY + vn / BX, gx = x0 + bxb * BX + vn % BX;
         bool ok = gz < D && gy < H && gx < W;
         bf16* yp = y + ((((int64_t)n * D + gz) * H + gy) * W + gx) * ycs + cobBase * 16 + g * 4;
+        bf16x4 oc[COB];
 #pragma unroll
         for (int c = 0; c < COB; c++) {
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = acc[r][c][j] + (bias ? bias[(cobBase + c) * 16 + g * 4 + j] : 0.f);
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu & 1) v = fmaxf(v, 0.f);
                 o[j] = (bf16)v;
                 if (STATS && ok) { float q = (float)o[j]; s1[c][j] += q; s2[c][j] += q * q; }
             }
-            if (ok) *reinterpret_cast<bf16x4*>(yp + c * 16) = o;
+            oc[c] = o;
         }
+        if constexpr (COB == 2) {
+            if (relu & 2) {
+                // wide store (round 4): the lane's two 4-channel pieces (output blocks 0 and 1 of ONE voxel) trade halves with the
+                // neighbouring 16-lane rows (v_permlane16_swap); lane (vn, g) then holds channels (g & 1) * 16 + (g >> 1) * 8 .. + 7:
+                // one 16-B store per lane, the voxel's 64 B written by four lanes
+                typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+                typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+                u32x2 u0 = __builtin_bit_cast(u32x2, oc[0]), u1 = __builtin_bit_cast(u32x2, oc[1]);
+                u32x2 p0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
+                u32x2 p1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
+                u32x4 wv = {p0[0], p1[0], p0[1], p1[1]};
+                if (ok) *reinterpret_cast<u32x4*>(yp - g * 4 + (g & 1) * 16 + (g >> 1) * 8) = wv;
+                continue;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < COB; c++)
+            if (ok) *reinterpret_cast<bf16x4*>(yp + c * 16) = oc[c];
     }
     if constexpr (STATS) {
 #pragma unroll
@@ -1340,13 +1359,13 @@ int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bia
         MI3D_LAUNCH_CHECK();
         if (defer_finish) return 0;
         int64_t tot = g.M() * (Cout / 8);
-        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ksplit, g.M(), Cout, bias, y, ycs, relu);
+        splitk_finish_kernel<<<cdiv(tot, BLK) > 2048 ? 2048 : cdiv(tot, BLK), BLK, 0, s>>>(skws, ksplit, g.M(), Cout, bias, y, ycs, relu & 1);
     } else if (part) {
         if (w8) LC8(true, false, part, bias, relu);
-        else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part, relu);
+        else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, true, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, part, relu & 1);
     } else {
         if (w8) LC8(false, false, nullptr, bias, relu);
-        else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr, relu);
+        else conv3_mfma_kernel<TZ, TYB, TXB, BX, COB, false, false><<<grid, BLK, 0, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W, tz, ty, tx, nullptr, relu & 1);
     }
 #undef LC8
 #undef LC8X
@@ -1497,6 +1516,8 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         return 0;
     }
     int ks = skws ? pick_ksplit(Cin, Cout, g, ks_target) : 1;
+    // bit 1 of the relu word: 16-byte epilogue stores in the eight-wave kernels (two output blocks per workgroup)
+    if (!mi3d_routes().no_wide_store && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0 && Cout % 32 == 0) relu |= 2;
     if (ks > 1) MI3D_CHECK_ARG(ycs % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv3_mfma_fwd: split-K needs 16-B aligned output rows");
     if (big_geo(g)) {
         // (round 4: ONE 16-channel output block per workgroup at the 16-wide levels -- twice the workgroups, half the chain each, the

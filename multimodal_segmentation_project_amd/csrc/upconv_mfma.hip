@@ -52,7 +52,7 @@ __global__ void upconv_pack_mfma_kernel(const float* __restrict__ w, int Cin, in
 template <int KS>
 __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __restrict__ x, int xcs, const bf16* __restrict__ wf,
                                                               const float* __restrict__ bias, bf16* __restrict__ y, int ycs,
-                                                              int Cout, int N, int D, int H, int W) {
+                                                              int Cout, int N, int D, int H, int W, int wide) {
     int64_t M = (int64_t)N * D * H * W;
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, vn = lane & 15, G = lane >> 4;
     int COBN = Cout / 16;
@@ -74,6 +74,41 @@ __global__ __launch_bounds__(BLK) void upconv_mfma_fwd_kernel(const bf16* __rest
         for (int ks = 0; ks < KS; ks++) Bf[ks] = *reinterpret_cast<const bf16x8*>(x + vc * xcs + 32 * ks + 8 * G);
         // 32-bit index math (M < 2^31 checked by the launcher): 64-bit div/mod cost ~80 instructions each
         unsigned vu = (unsigned)vc; int w_ = (int)(vu % (unsigned)W); unsigned r = vu / (unsigned)W; int h_ = (int)(r % (unsigned)H); r /= (unsigned)H; int d_ = (int)(r % (unsigned)D); int n = (int)(r / (unsigned)D);
+        if (wide) {
+            // wide stores (round 4; all 8 taps in this workgroup, ycs % 8 == 0): the taps c = 0 and c = 1 of one (a, b) are the two
+            // x-neighbours 2w and 2w + 1 of the output.  Their two results trade halves through v_permlane16_swap; afterwards lane
+            // (vn, G) holds channels (G >> 1) * 8 .. + 7 of voxel 2w + (G & 1): one 16-B store per lane, 64 contiguous bytes per input
+            // voxel and 1 KB per wave instead of 8-B pieces with a 64-B stride
+            typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+            typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+#pragma unroll
+            for (int ab = 0; ab < 4; ab++) {
+                int a = ab >> 1, b = ab & 1;
+                bf16* yq = y + ((((int64_t)n * 2 * D + 2 * d_ + a) * 2 * H + 2 * h_ + b) * 2 * W + 2 * w_ + (G & 1)) * ycs + (G >> 1) * 8;
+                for (int cob = blockIdx.y; cob < COBN; cob += gridDim.y) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    const bf16* wp0 = wf + (((int64_t)(2 * ab) * COBN + cob) * KS) * 512 + lane * 8;
+                    const bf16* wp1 = wf + (((int64_t)(2 * ab + 1) * COBN + cob) * KS) * 512 + lane * 8;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks++) {
+                        acc0 = mfma16(hoist ? wh[2 * ab] : *reinterpret_cast<const bf16x8*>(wp0 + ks * 512), Bf[ks], acc0);
+                        acc1 = mfma16(hoist ? wh[2 * ab + 1] : *reinterpret_cast<const bf16x8*>(wp1 + ks * 512), Bf[ks], acc1);
+                    }
+                    bf16x4 o0, o1;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float bj = bias ? bias[cob * 16 + 4 * G + j] : 0.f;
+                        o0[j] = (bf16)(acc0[j] + bj); o1[j] = (bf16)(acc1[j] + bj);
+                    }
+                    u32x2 u0 = __builtin_bit_cast(u32x2, o0), u1 = __builtin_bit_cast(u32x2, o1);
+                    u32x2 p0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
+                    u32x2 p1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
+                    u32x4 wv = {p0[0], p1[0], p0[1], p1[1]};
+                    if (ok) *reinterpret_cast<u32x4*>(yq + cob * 16) = wv;
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int tap = 0; tap < 8; tap++) {
             // few voxels (deep levels): the launcher spreads the 8 taps over blockIdx.z -> 8x shorter dependent chain
@@ -421,7 +456,8 @@ int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const floa
     while (gx * gy < 512 && gy < Cout / 16) gy *= 2;      // few voxels (deep levels): parallelise over channel blocks
     int gz = (gx * gy < 512 && !(Cin == 32 && Cout == 16)) ? 8 : 1;     // ... and over the 8 taps
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
-#define UF(K) upconv_mfma_fwd_kernel<K><<<grid, BLK, 0, s>>>(xp, xcs, wf, bias, yp, ycs, Cout, g.N, g.D, g.H, g.W)
+    const int wide = (gz == 1 && ycs % 8 == 0 && ((uintptr_t)yp % 16) == 0 && !mi3d_routes().no_wide_store) ? 1 : 0;
+#define UF(K) upconv_mfma_fwd_kernel<K><<<grid, BLK, 0, s>>>(xp, xcs, wf, bias, yp, ycs, Cout, g.N, g.D, g.H, g.W, wide)
     switch (Cin / 32) { case 1: UF(1); break; case 2: UF(2); break; case 4: UF(4); break; default: UF(8); break; }
 #undef UF
     MI3D_LAUNCH_CHECK();
