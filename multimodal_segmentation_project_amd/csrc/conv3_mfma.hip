@@ -331,18 +331,34 @@ __device__ __forceinline__ void conv3_mfma_body(Bid bid_, const bf16* __restrict
         int gz = z0 + bz, gy = y0 + byb * BY + vn / BX, gx = x0 + bxb * BX + vn % BX;
         bool ok = gz < D && gy < H && gx < W;
         bf16* yp = y + ((((int64_t)n * D + gz) * H + gy) * W + gx) * ycs + cobBase * 16 + g * 4;
+        bf16x4 oc[COB];
 #pragma unroll
         for (int c = 0; c < COB; c++) {
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = acc[r][c][j] + (bias ? bias[(cobBase + c) * 16 + g * 4 + j] : 0.f);
-                if (relu) v = fmaxf(v, 0.f);           // inference: BatchNorm folded into (weights, bias), ReLU here
+                if (relu & 1) v = fmaxf(v, 0.f);       // inference: BatchNorm folded into (weights, bias), ReLU here
                 o[j] = (bf16)v;
                 if (STATS && ok) { float q = (float)o[j]; s1[c][j] += q; s2[c][j] += q * q; }
             }
-            if (ok) *reinterpret_cast<bf16x4*>(yp + c * 16) = o;
+            oc[c] = o;
         }
+        if constexpr (COB == 2) {
+            if (relu & 2) {          // wide store: see conv3_mfma8_kernel
+                typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+                typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+                u32x2 u0 = __builtin_bit_cast(u32x2, oc[0]), u1 = __builtin_bit_cast(u32x2, oc[1]);
+                u32x2 p0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
+                u32x2 p1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
+                u32x4 wv = {p0[0], p1[0], p0[1], p1[1]};
+                if (ok) *reinterpret_cast<u32x4*>(yp - g * 4 + (g & 1) * 16 + (g >> 1) * 8) = wv;
+                continue;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < COB; c++)
+            if (ok) *reinterpret_cast<bf16x4*>(yp + c * 16) = oc[c];
     }
     if constexpr (STATS) {
 #pragma unroll
@@ -1790,6 +1806,7 @@ struct FusedArgs {
     const bf16* dxin; int dxcs_in, dCin; const bf16* dwp; bf16* dyout; int dycs_out, dCout; int dtZ, dtY, dtX; float* dpart;
     int dgx, dgy, dgz;
     int N, D, H, W;
+    int flags;                // bit 1: 16-byte epilogue stores in the input-gradient half
 };
 // Full-resolution variant: the input-gradient conv is the persistent kernel body.  Both halves are persistent with ONE
 // workgroup per CU each, so every CU runs one MFMA-heavy dgrad workgroup beside one staging/LDS-heavy wgrad workgroup
@@ -1847,14 +1864,14 @@ __global__ __launch_bounds__(BLK, 2) void conv3_bwd_fused_kernel(FusedArgs a) {
             int f = xcd_contig(b, a.dgx * a.dgy);
             Bid v{f / a.dgy, f % a.dgy, 0, a.dgx, a.dgy, 1, true};
             conv3_mfma_body<4, 8, 1, 16, 2, false, false, true>(v, a.dxin, a.dxcs_in, a.dCin, a.dwp, nullptr, a.dyout, a.dycs_out, a.dCout,
-                                                                a.D, a.H, a.W, a.dtZ, a.dtY, a.dtX, nullptr, fused_lds);
+                                                                a.D, a.H, a.W, a.dtZ, a.dtY, a.dtX, nullptr, fused_lds, a.flags);
             return;
         }
         Bid v{b % a.dgx, (b / a.dgx) % a.dgy, b / (a.dgx * a.dgy), a.dgx, a.dgy, a.dgz};
         if constexpr (BIG) {}
         else
             conv3_mfma_body<4, 2, 2, 4, 2, false, SPLITK, true>(v, a.dxin, a.dxcs_in, a.dCin, a.dwp, nullptr, a.dyout, a.dycs_out, a.dCout,
-                                                                a.D, a.H, a.W, a.dtZ, a.dtY, a.dtX, a.dpart, fused_lds);
+                                                                a.D, a.H, a.W, a.dtZ, a.dtY, a.dtX, a.dpart, fused_lds, a.flags);
     }
 }
 
@@ -2084,6 +2101,7 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
         bool okzx = gz < D && gx < W;
         bf16* yrow = y + ((((int64_t)n * D + gz) * H + y0) * W + gx) * ycs + co0 + kg * 4;
         int wbase = wave * WIY * C1F_LD;
+        bf16x4 oprev;
 #pragma unroll
         for (int r = 0; r < WTY; r++) {
             int rb = wbase + r * C1F_LD;
@@ -2099,10 +2117,27 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = acc[j] + bv[j];
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu & 1) v = fmaxf(v, 0.f);
                 o[j] = (bf16)v;
                 float q = ok ? (float)o[j] : 0.f;
                 s1[j] += q; s2[j] = fmaf(q, q, s2[j]);
+            }
+            if (relu & 2) {
+                // wide stores (round 4): rows r - 1 and r trade halves (v_permlane16_swap); lane (vn, kg) then holds channels
+                // (kg >> 1) * 8 .. + 7 of the voxel in row r - 1 + (kg & 1): one 16-B store per lane and row pair
+                if (r & 1) {
+                    typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+                    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+                    u32x2 u0 = __builtin_bit_cast(u32x2, oprev), u1 = __builtin_bit_cast(u32x2, o);
+                    u32x2 p0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
+                    u32x2 p1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
+                    u32x4 wv = {p0[0], p1[0], p0[1], p1[1]};
+                    const int rr = r - 1 + (kg & 1);
+                    if (okzx && (y0 + rr) < H)
+                        *reinterpret_cast<u32x4*>(yrow - kg * 4 + (kg >> 1) * 8 + (int64_t)rr * W * ycs) = wv;
+                } else
+                    oprev = o;
+                continue;
             }
             if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs) = o;
         }
@@ -2363,6 +2398,7 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     a.dCout = Cin; a.dtZ = cdiv(g.D, 4); a.dtY = cdiv(g.H, 8); a.dtX = cdiv(g.W, big ? 16 : 8); a.dpart = ks > 1 ? skws : nullptr;
     a.dgx = g.N * a.dtZ * a.dtY * a.dtX; a.dgy = Cin / 32; a.dgz = ks;
     a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
+    a.flags = (!mi3d_routes().no_wide_store && dxcs % 8 == 0 && ((uintptr_t)dx % 16) == 0) ? 2 : 0;
     size_t lds = (size_t)(WNV + WNH) * 32;
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
     MI3D_SET_MAX_LDS_ONCE((&conv3_bwd_fused_kernel<false, true>), lds);
@@ -2427,6 +2463,8 @@ int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y
                       hipStream_t s, const float* wscale, int relu) {
     MI3D_CHECK_ARG(Cout % 16 == 0 && ycs % 4 == 0 && ((uintptr_t)y % 8) == 0, "conv3_c1_fwd_mfma: unsupported channels");
     dim3 grid((unsigned)conv3_c1_fwd_stat_blocks(g), (unsigned)(Cout / 16));
+    // bit 1 of the relu word: 16-byte epilogue stores (row pairs trade halves through v_permlane16_swap)
+    if (!mi3d_routes().no_wide_store && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0) relu |= 2;
     conv3_c1_fwd_mfma_kernel<<<grid, BLK, 0, s>>>(x, w, bias, (bf16*)y, ycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ),
                                                   cdiv(g.H, WTY), cdiv(g.W, WTX), part, wscale, relu);
     MI3D_LAUNCH_CHECK();
