@@ -784,6 +784,7 @@ __global__ __launch_bounds__(C1W * 64) void head_loss_bwd_mfma_kernel(const bf16
     int vn = lane & 15, kg = lane >> 4;
     const bf16* zn = z + (int64_t)n * V * zcs;
     bf16* dzn = dz ? dz + (int64_t)n * V * dzcs : nullptr;
+    const bool wide_dz = dzn && (dzcs & 7) == 0 && (reinterpret_cast<uintptr_t>(dzn) & 15) == 0;       // uniform: 16-byte dz stores
     const int64_t* lb = labels + (int64_t)n * V;
     const float* tg = TEACH ? teacher + (int64_t)n * Cout * V : nullptr;
     float go = grad_out ? grad_out[0] : 1.f;
@@ -844,6 +845,7 @@ __global__ __launch_bounds__(C1W * 64) void head_loss_bwd_mfma_kernel(const bf16
 #pragma unroll
                 for (int j = 0; j < 8; j++) { bd[j] = (bf16)t8[j]; dbs += t8[j]; }
             }
+            bf16x4 obn[2];
 #pragma unroll
             for (int nb = 0; nb < 2; nb++) {
                 int64_t v = vc + nb * 16 + vn;
@@ -851,10 +853,20 @@ __global__ __launch_bounds__(C1W * 64) void head_loss_bwd_mfma_kernel(const bf16
                 if (v < V && kg < Cout) bl[0] = (bf16)dlt[wave][hh][kg * 32 + nb * 16 + vn];
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
                 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw, bl, o, 0, 0, 0);
-                if (dzn && v < V) {
-                    bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
-                    *reinterpret_cast<bf16x4*>(dzn + v * dzcs + 4 * kg) = ob;
-                }
+                obn[nb] = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                if (!wide_dz && dzn && v < V) *reinterpret_cast<bf16x4*>(dzn + v * dzcs + 4 * kg) = obn[nb];
+            }
+            if (wide_dz) {
+                // 16-byte stores (round 4): the two 16-voxel groups trade halves (v_permlane16_swap); lane (vn, kg) then holds channels
+                // (kg >> 1) * 8 .. + 7 of voxel vc + (kg & 1) * 16 + vn
+                typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+                typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+                u32x2 u0 = __builtin_bit_cast(u32x2, obn[0]), u1 = __builtin_bit_cast(u32x2, obn[1]);
+                u32x2 p0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
+                u32x2 p1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
+                u32x4 wv = {p0[0], p1[0], p0[1], p1[1]};
+                const int64_t vw = vc + (kg & 1) * 16 + vn;
+                if (vw < V) *reinterpret_cast<u32x4*>(dzn + vw * dzcs + (kg >> 1) * 8) = wv;
             }
             bf16x8 az = tr_frag_h(reinterpret_cast<const char*>(zt[wave][hh]), laneK);
             accW = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az, bd, accW, 0, 0, 0);
