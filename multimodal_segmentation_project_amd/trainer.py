@@ -483,6 +483,11 @@ class TrainStep(_StepBase):
                 live = any(t and lo <= o < hi for o, t in zip(self.arena.offsets, trainable))
                 if live and last >= 0:
                     sched.setdefault(min(seg, last), []).append(seg)
+            if os.environ.get("MI3D_COMM_SERIAL") and sched and last >= 0:
+                # every bucket behind the last segment, on the compute stream: no second hardware queue in the step at all (any
+                # kernel on another queue costs this step 100-250 us on this runtime, profiles/r04_experiments_second_queue.txt),
+                # at the price of an all-reduce that hides under nothing
+                sched = {last: [b for sg in sorted(sched) for b in sched[sg]]}
             st["comm_after"] = sched
             if self.teacher is not None:
                 st["t_ws"] = torch.empty(st["ws_bytes"], dtype=torch.uint8, device=dev)
