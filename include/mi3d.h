@@ -171,7 +171,10 @@ const char* mi3d_debug_route_name(int index);
  * (bench.py --emulate-comm: what a collective beside the encoder backward costs the persistent grids). */
 int mi3d_debug_occupy_cus(int workgroups, int microseconds, float* buf, int64_t n, void* stream);
 /* mi3d_set_cu_budget: CUs (0..128) the persistent conv grids launched from the calling thread leave free for a collective
- * kernel that is resident beside them (TrainStep sets it for the backward segments that overlap a gradient exchange). */
+ * kernel that is resident beside them (TrainStep sets it for the backward segments that overlap a gradient exchange).
+ * THREAD-LOCAL: it applies to launches made by the thread that set it (a backward run by another thread, e.g. the autograd engine's,
+ * does not see it), and a hipGraph capture freezes the value that was active while it was captured.  The grids are sized from the
+ * device's compute-unit count (hipDeviceAttributeMultiprocessorCount, read once per process). */
 int mi3d_set_cu_budget(int cus);
 int mi3d_timing_event_create(void** event_out);
 int mi3d_time_next_conv3_kernel(void* start_event, void* stop_event, int kind, int Cin, int Cout);
