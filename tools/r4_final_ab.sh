@@ -1,5 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python tools/abenv.py overlap= serial=MI3D_COMM_SERIAL=1 --rounds 3 --noprof --bench-args "--force-comm" 2>&1 | tee gpurun_out/r4_comm_serial.log
-python tools/abenv.py nocomm= --rounds 3 --noprof --bench-args "--no-aux-wgrad" 2>&1 | tee -a gpurun_out/r4_comm_serial.log
-python -m pytest tests/test_gpu_dp.py -x -q 2>&1 | tail -2
+for e in "X=1" "GPU_MAX_HW_QUEUES=1" "GPU_MAX_HW_QUEUES=8" "HSA_ENABLE_INTERRUPT=0" "ROC_ACTIVE_WAIT_TIMEOUT=1000" "HIP_FORCE_DEV_KERNARG=0" "DEBUG_CLR_USE_STDMUTEX_IN_AMD_MONITOR=1" "HSA_ENABLE_SDMA=0" "AMD_DIRECT_DISPATCH=0"; do
+  echo "== $e" | tee -a gpurun_out/r4_poke_env.log
+  env $e python tools/poke_step.py 2>&1 | grep "plain" | tee -a gpurun_out/r4_poke_env.log
+done
