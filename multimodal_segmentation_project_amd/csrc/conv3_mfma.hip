@@ -2101,7 +2101,6 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
         bool okzx = gz < D && gx < W;
         bf16* yrow = y + ((((int64_t)n * D + gz) * H + y0) * W + gx) * ycs + co0 + kg * 4;
         int wbase = wave * WIY * C1F_LD;
-        bf16x4 oprev;
 #pragma unroll
         for (int r = 0; r < WTY; r++) {
             int rb = wbase + r * C1F_LD;
@@ -2117,28 +2116,13 @@ __global__ __launch_bounds__(BLK) void conv3_c1_fwd_mfma_kernel(const float* __r
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v = acc[j] + bv[j];
-                if (relu & 1) v = fmaxf(v, 0.f);
+                if (relu) v = fmaxf(v, 0.f);
                 o[j] = (bf16)v;
                 float q = ok ? (float)o[j] : 0.f;
                 s1[j] += q; s2[j] = fmaf(q, q, s2[j]);
             }
-            if (relu & 2) {
-                // wide stores (round 4): rows r - 1 and r trade halves (v_permlane16_swap); lane (vn, kg) then holds channels
-                // (kg >> 1) * 8 .. + 7 of the voxel in row r - 1 + (kg & 1): one 16-B store per lane and row pair
-                if (r & 1) {
-                    typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
-                    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
-                    u32x2 u0 = __builtin_bit_cast(u32x2, oprev), u1 = __builtin_bit_cast(u32x2, o);
-                    u32x2 p0 = __builtin_amdgcn_permlane16_swap(u0[0], u1[0], false, false);
-                    u32x2 p1 = __builtin_amdgcn_permlane16_swap(u0[1], u1[1], false, false);
-                    u32x4 wv = {p0[0], p1[0], p0[1], p1[1]};
-                    const int rr = r - 1 + (kg & 1);
-                    if (okzx && (y0 + rr) < H)
-                        *reinterpret_cast<u32x4*>(yrow - kg * 4 + (kg >> 1) * 8 + (int64_t)rr * W * ycs) = wv;
-                } else
-                    oprev = o;
-                continue;
-            }
+            // (round 4: 16-byte stores through row pairs, as in the persistent conv, measured slower here -- 23.5 -> 28.0 us: the kernel is
+            // one MFMA pair per row and the pairing serialises two rows)
             if (ok) *reinterpret_cast<bf16x4*>(yrow + (int64_t)r * W * ycs) = o;
         }
     }
@@ -2463,8 +2447,6 @@ int conv3_c1_fwd_mfma(const float* x, const float* w, const float* bias, void* y
                       hipStream_t s, const float* wscale, int relu) {
     MI3D_CHECK_ARG(Cout % 16 == 0 && ycs % 4 == 0 && ((uintptr_t)y % 8) == 0, "conv3_c1_fwd_mfma: unsupported channels");
     dim3 grid((unsigned)conv3_c1_fwd_stat_blocks(g), (unsigned)(Cout / 16));
-    // bit 1 of the relu word: 16-byte epilogue stores (row pairs trade halves through v_permlane16_swap)
-    if (!mi3d_routes().no_wide_store && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0) relu |= 2;
     conv3_c1_fwd_mfma_kernel<<<grid, BLK, 0, s>>>(x, w, bias, (bf16*)y, ycs, Cout, g.N, g.D, g.H, g.W, cdiv(g.D, WTZ),
                                                   cdiv(g.H, WTY), cdiv(g.W, WTX), part, wscale, relu);
     MI3D_LAUNCH_CHECK();

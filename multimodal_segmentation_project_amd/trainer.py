@@ -222,7 +222,20 @@ class _StepBase:
         self.comm.broadcast_parameters(self.model.buffers())
 
     def sync_buffers(self):
+        self.check_exchange()
         self.comm.sync_buffers(self.model.buffers())
+
+    def check_exchange(self):
+        """The compute stream joins the exchange stream through a counter in memory (mi3d_flag_wait); a waiter that gave up after
+        its 2 s bound -- a collective that never finished -- stored the value it was waiting for in the error word.  This reads the
+        word (one host synchronisation): called at the points that synchronise anyway (sync_buffers, and through it evaluate()), never inside a
+        step; call it yourself before trusting a checkpoint.  Raises instead of letting a step that used stale gradients go unnoticed."""
+        f = getattr(self, "_comm_flag", None)
+        if f is not None:
+            bad = int(f[1].item())
+            if bad != 0:
+                raise Mi3dError(f"gradient exchange of step {bad} did not finish within the join's time bound: the optimizer step "
+                                f"behind it used incomplete gradients (dead rank / hung collective?)")
 
     # ---- exchange points
     def _on_comm_stream(self, fn):
