@@ -71,7 +71,7 @@ void mi3d_set_error(const char* fmt, ...);
     X(defer_mask, 7)        /* which weight gradients go to the aux stream: 1 decoder level 0, 2 decoder level 1, 4 deep levels */ \
     X(apply_on_load, 0)     /* MI3D_EXPERIMENTS builds only (round 4, measured slower): deep levels apply BatchNorm in the next conv's staging pass instead of a bn_apply / bn_bwd_apply launch */ \
     X(no_pool_splitk, 0)    /* 1: a split-K gradient of a pooled tensor is finished by its own pass, not inside the MaxPool3d backward */ \
-    X(no_wide_store, 0)     /* 1: persistent conv epilogue with two 8-byte stores per lane and row pair instead of one 16-byte store */ \
+    X(no_wide_store, 4)     /* bit mask of the kernels that keep 8-byte epilogue stores instead of 16-byte ones (v_permlane16_swap): 1 persistent conv, 2 eight-wave conv, 4 four-wave conv body of the fused backward, 8 transposed-conv forward; 15 = all.  In-process A/B of each site (us/step gained by the wide store): 0 / 5 / -3 / 7, so the four-wave body keeps its 8-byte stores */ \
     X(no_pool_pair, 0)      /* 1: MaxPool3d backward with one thread per window (rounds 1-3) instead of two */ \
     X(no_wgrad_xcd, 0)      /* 1: full-resolution weight gradients take tile = slab index (rounds 1-3) instead of XCD-contiguous tiles */ \
     X(no_upbwd_xcd_mix, 0)  /* 1: fused transposed-conv backward with the round-3 block mapping (even blocks weight gradient, odd data gradient: one kind per XCD) */ \

@@ -1492,7 +1492,7 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     if (persist_ok(Cin, Cout, g)) {
         int tz = cdiv(g.D, 4), ty = cdiv(g.H, 8), tx = cdiv(g.W, 16), nt = g.N * tz * ty * tx, grid = persist_grid(Cin, Cout, g);
         // bit 1 of the relu word: 16-byte epilogue stores (two M-block rows trade halves through v_permlane16_swap)
-        if (!mi3d_routes().no_wide_store && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0 && yh.delta % 8 == 0) relu |= 2;
+        if (!(mi3d_routes().no_wide_store & 1) && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0 && yh.delta % 8 == 0) relu |= 2;
 #define PK(COB_, NCH_)                                                                                                         \
         do {                                                                                                                   \
             hipEvent_t tev0 = nullptr, tev1 = nullptr;                                                                          \
@@ -1533,7 +1533,7 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
     }
     int ks = skws ? pick_ksplit(Cin, Cout, g, ks_target) : 1;
     // bit 1 of the relu word: 16-byte epilogue stores in the eight-wave kernels (two output blocks per workgroup)
-    if (!mi3d_routes().no_wide_store && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0 && Cout % 32 == 0) relu |= 2;
+    if (!(mi3d_routes().no_wide_store & 2) && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0 && Cout % 32 == 0) relu |= 2;
     if (ks > 1) MI3D_CHECK_ARG(ycs % 8 == 0 && ((uintptr_t)y % 16) == 0, "conv3_mfma_fwd: split-K needs 16-B aligned output rows");
     if (big_geo(g)) {
         // (round 4: ONE 16-channel output block per workgroup at the 16-wide levels -- twice the workgroups, half the chain each, the
@@ -2315,7 +2315,7 @@ int conv3_mfma_bwd_fused_persist(const void* x, int xcs, int Cin, const void* dy
     a.pgrid = a.pnt < pcap ? a.pnt : pcap; a.dyh = dxh;
     a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
     a.xcd_tiles = mi3d_routes().no_wgrad_xcd ? 0 : 1;
-    a.flags = (!mi3d_routes().no_wide_store && dxcs % 8 == 0 && ((uintptr_t)dx % 16) == 0 && dxh.delta % 8 == 0) ? 2 : 0;
+    a.flags = (!(mi3d_routes().no_wide_store & 1) && dxcs % 8 == 0 && ((uintptr_t)dx % 16) == 0 && dxh.delta % 8 == 0) ? 2 : 0;
     int nw = a.wgx * a.wgy * a.wgz;
     int half = nw > a.pgrid ? nw : a.pgrid;
     unsigned nblk = (unsigned)(2 * half);
@@ -2382,7 +2382,7 @@ int conv3_mfma_bwd_fused(const void* x, int xcs, int Cin, const void* dy, int dy
     a.dCout = Cin; a.dtZ = cdiv(g.D, 4); a.dtY = cdiv(g.H, 8); a.dtX = cdiv(g.W, big ? 16 : 8); a.dpart = ks > 1 ? skws : nullptr;
     a.dgx = g.N * a.dtZ * a.dtY * a.dtX; a.dgy = Cin / 32; a.dgz = ks;
     a.N = g.N; a.D = g.D; a.H = g.H; a.W = g.W;
-    a.flags = (!mi3d_routes().no_wide_store && dxcs % 8 == 0 && ((uintptr_t)dx % 16) == 0) ? 2 : 0;
+    a.flags = (!(mi3d_routes().no_wide_store & 4) && dxcs % 8 == 0 && ((uintptr_t)dx % 16) == 0) ? 2 : 0;
     size_t lds = (size_t)(WNV + WNH) * 32;
     if (lds < 16 * 1024 + 256) lds = 16 * 1024 + 256;
     MI3D_SET_MAX_LDS_ONCE((&conv3_bwd_fused_kernel<false, true>), lds);

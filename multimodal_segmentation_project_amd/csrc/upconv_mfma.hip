@@ -456,7 +456,7 @@ int upconv2_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const floa
     while (gx * gy < 512 && gy < Cout / 16) gy *= 2;      // few voxels (deep levels): parallelise over channel blocks
     int gz = (gx * gy < 512 && !(Cin == 32 && Cout == 16)) ? 8 : 1;     // ... and over the 8 taps
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
-    const int wide = (gz == 1 && ycs % 8 == 0 && ((uintptr_t)yp % 16) == 0 && !mi3d_routes().no_wide_store) ? 1 : 0;
+    const int wide = (gz == 1 && ycs % 8 == 0 && ((uintptr_t)yp % 16) == 0 && !(mi3d_routes().no_wide_store & 8)) ? 1 : 0;
 #define UF(K) upconv_mfma_fwd_kernel<K><<<grid, BLK, 0, s>>>(xp, xcs, wf, bias, yp, ycs, Cout, g.N, g.D, g.H, g.W, wide)
     switch (Cin / 32) { case 1: UF(1); break; case 2: UF(2); break; case 4: UF(4); break; default: UF(8); break; }
 #undef UF
