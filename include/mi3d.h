@@ -131,12 +131,11 @@ int mi3d_unet_pack_from(const mi3d_unet_desc* d, const void* const* params, void
  * host round trip); the exchange stream waits for the mark (mi3d_stream_wait_event) and all-reduces the bucket while the
  * remaining segments run.  Marks are consumed by that call. */
 int mi3d_unet_backward_marks(const int* segs, void* const* events, int n);
-/* Stream-to-stream ordering through a counter in device memory (flag = device int64[2], zero-initialised by the caller): a
- * hardware cross-queue wait costs the waiting stream 30-45 us on this runtime even for an event that fired long ago.
+/* Utilities: stream-to-stream ordering through a counter in device memory (flag = device int64[2], zero-initialised by the caller).
  * mi3d_flag_set: flag[0] = value once everything enqueued on `stream` so far has finished (one 1-thread kernel).
- * mi3d_flag_wait: `stream` continues when flag[0] >= value (one 1-wave kernel that polls; values must grow monotonically, e.g. a
- * step counter).  After timeout_us without it the waiter gives up and stores `value` in flag[1]: a caller that cannot rule out a
- * lost producer checks flag[1] afterwards.  Use only where the producing stream cannot depend on the waiting one. */
+ * mi3d_flag_wait: `stream` continues when flag[0] >= value (one 1-wave kernel that polls; values must grow monotonically).  After
+ * timeout_us without it the waiter gives up and stores `value` in flag[1].  Round 4 measured them as a replacement for the hardware
+ * cross-queue join of the data-parallel step: no gain; the step does not use them, tools/queue_probe.py does. */
 int mi3d_flag_set(int64_t* flag, int64_t value, void* stream);
 int mi3d_flag_wait(int64_t* flag, int64_t value, int64_t timeout_us, void* stream);
 int mi3d_stream_wait_event(void* stream, void* event);

@@ -170,7 +170,6 @@ class _StepBase:
         # the exchange stream must sit on another hardware queue than the compute stream (see concurrent_stream)
         self.comm_stream = concurrent_stream(self.device, role="comm") if self.do_comm else None
         self._mark_handles = []          # exchange-mark events (mi3d_unet_backward_marks)
-        self._comm_flag, self._comm_seq = None, 0          # memory-flag join with the exchange stream (mi3d_flag_set / _wait)
         self.use_graph = bool(use_graph)
         self._statics = {}
         self._static = None
@@ -222,20 +221,7 @@ class _StepBase:
         self.comm.broadcast_parameters(self.model.buffers())
 
     def sync_buffers(self):
-        self.check_exchange()
         self.comm.sync_buffers(self.model.buffers())
-
-    def check_exchange(self):
-        """The compute stream joins the exchange stream through a counter in memory (mi3d_flag_wait); a waiter that gave up after
-        its 2 s bound -- a collective that never finished -- stored the value it was waiting for in the error word.  This reads the
-        word (one host synchronisation): called at the points that synchronise anyway (sync_buffers, and through it evaluate()), never inside a
-        step; call it yourself before trusting a checkpoint.  Raises instead of letting a step that used stale gradients go unnoticed."""
-        f = getattr(self, "_comm_flag", None)
-        if f is not None:
-            bad = int(f[1].item())
-            if bad != 0:
-                raise Mi3dError(f"gradient exchange of step {bad} did not finish within the join's time bound: the optimizer step "
-                                f"behind it used incomplete gradients (dead rank / hung collective?)")
 
     # ---- exchange points
     def _on_comm_stream(self, fn):
@@ -664,15 +650,6 @@ class TrainStep(_StepBase):
                                     self.comm.average_(met)
                                 for k in b:
                                     self.comm.reduce_bucket(k)
-                        if not os.environ.get("MI3D_NO_FLAG_JOIN"):
-                            # the compute stream's join with the exchange stream: a counter in memory the exchange stream bumps
-                            # behind its last collective and a one-wave poll on the compute stream (mi3d_flag_wait), instead of a
-                            # hardware cross-queue wait (30-45 us on the waiting stream even when the event fired long ago)
-                            if self._comm_flag is None:
-                                self._comm_flag = torch.zeros(2, dtype=torch.int64, device=self.device)
-                            self._comm_seq += 1
-                            call("mi3d_flag_set", ptr(self._comm_flag), self._comm_seq, cs.cuda_stream)
-                            join_fn = lambda q=self._comm_seq: call("mi3d_flag_wait", ptr(self._comm_flag), q, 2_000_000, stream_ptr())
                     if exch and not last:
                         with_met, met_pending = met_pending, False
                         comm(lambda b=tuple(exch), wm=with_met: self._on_comm_stream(
