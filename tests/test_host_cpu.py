@@ -221,6 +221,42 @@ def test_kernel_roofline_tool_assigns_every_launch_of_the_committed_timeline(tmp
             assert float(row["algo_MB"]) > 0 and row["layer"], row
 
 
+@pytest.mark.parametrize("rnd", ["r03", "r04"])
+def test_kernel_roofline_tool_on_every_committed_round(tmp_path, rnd):
+    """The same check on each round's committed single-stream timeline (round 4 added kernel families: the paired pool kernels)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tl, pmc = os.path.join(root, "profiles", rnd + "_step_timeline.txt"), os.path.join(root, "profiles", rnd + "_pmc_step_traffic.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_roofline.py"), tl, pmc, "--out", str(tmp_path / "r.csv")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert " 0 unassigned" in r.stdout, r.stdout.splitlines()[0]
+
+
+def test_bench_roofline_candidates_have_committed_traffic_records():
+    """bench.py reports `roofline.traffic` from profiles/roofline_kernel_traffic.json (PMC passes cannot run inside the bench process):
+    every candidate that can be the dominant launch of the default route has a record keyed like the candidate, with counter bytes
+    no smaller than its algorithmic bytes, and the lookup honours its time guard."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    rec = json.load(open(os.path.join(root, "profiles", "roofline_kernel_traffic.json")))["records"]
+    cands = {c["key"]: c for c in bench.roofline_candidates(96, 2)}
+    assert {c["stream"] for c in cands.values()} == {"compute", "aux"}
+    for key in ("wgrad_dec3_conv0", "dgrad_dec3_conv0", "fwd_dec3_conv0", "bwd_enc0_conv1_fused"):
+        assert key in rec and rec[key]["algorithmic_bytes_per_launch"] == cands[key]["bytes"]
+        assert rec[key]["hbm_bytes_per_launch"] >= 0.95 * cands[key]["bytes"]
+        ms = rec[key]["ms_per_launch_when_measured"]
+        assert bench._kernel_traffic(key, ms) == rec[key]["hbm_bytes_per_launch"]
+        assert bench._kernel_traffic(key, 2.0 * ms) is None          # a kernel that changed: no stale number
+    assert bench._kernel_traffic("no_such_kernel", 0.1) is None
+
+
 def test_route_switches_are_read_once_and_set_through_the_abi():
     """Every kernel-selection switch lives in one struct (csrc/common.h MI3D_ROUTE_LIST): the environment is read at first use
     only, later changes go through mi3d_debug_set_route; unknown names fail loudly."""
