@@ -196,9 +196,54 @@ __device__ __forceinline__ void rows_sum(const float* __restrict__ part, int nro
     }
 }
 
+// The same sum for a WIDE workgroup (round 4, NT = 1024 threads, <= 1024 rows): the consumers of the full-resolution layers run
+// as a few fat workgroups (<= 2 per CU) so that the rows are pulled from the L2 a few hundred times instead of 2048 times, and
+// the combine is two LDS stages (4 values per thread, then NT / 2C per (k, channel)) instead of one thread per channel walking
+// NT / (C / 4) lines.  red: [NT * 4] doubles, reused for the stage-two partials.  Result for threads < C in out[2].
+constexpr int WIDE_J = 8;
+template <int NT>
+__device__ __forceinline__ void rows_sum_wide(const float* __restrict__ part, int nrows, int C, double* red, double (&out)[2]) {
+    // ALL of a thread's pieces are requested before the first is used: one trip to the L2 / memory (the rows were written by
+    // another kernel's workgroups on all eight XCDs).  A counted loop of dependent round trips cost 6 us here.  The launcher
+    // guarantees nrows * C <= WIDE_J * NT * 2 (at most WIDE_J pieces per thread).
+    const int total4 = (nrows * 2 * C) >> 2;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + threadIdx.x;
+    f32x4 v[WIDE_J];
+#pragma unroll
+    for (int u = 0; u < WIDE_J; u++) {
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u * NT + (int)threadIdx.x < total4) v[u] = p4[(size_t)u * NT];
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < WIDE_J; u++) { acc[0] += (double)v[u][0]; acc[1] += (double)v[u][1]; acc[2] += (double)v[u][2]; acc[3] += (double)v[u][3]; }
+    // flat view: thread t holds elements 4t .. 4t+3 of a [NT * 4 / 2C][2C] array whose column kc = k * C + channel
+#pragma unroll
+    for (int i = 0; i < 4; i++) red[threadIdx.x * 4 + i] = acc[i];
+    __syncthreads();
+    const int C2 = 2 * C, lines = (NT * 4) / C2, S = NT / C2;      // S threads per column, lines / S (= 4) values each
+    const int kc = threadIdx.x % C2, sidx = threadIdx.x / C2;
+    double t = 0.0;
+    if (sidx < S)
+        for (int L = sidx; L < lines; L += S) t += red[L * C2 + kc];
+    __syncthreads();
+    if (sidx < S) red[sidx * C2 + kc] = t;
+    __syncthreads();
+    if (threadIdx.x < C) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            double u = 0.0;
+            for (int q = 0; q < S; q++) u += red[q * C2 + k * C + threadIdx.x];
+            out[k] = u;
+        }
+    }
+}
+
+template <int NT = BLK>
 __device__ __forceinline__ void bn_train_coeffs(const BnPart& t, int C, float* stat, float* ab /* [2][MAXC_BN] */, double* red) {
     double sq[2];
-    rows_sum(t.part, t.nrows, C, red, sq);
+    if constexpr (NT == BLK) rows_sum(t.part, t.nrows, C, red, sq);
+    else rows_sum_wide<NT>(t.part, t.nrows, C, red, sq);
     int c = threadIdx.x;
     if (c < C) {
         double mean = sq[0] / (double)t.M;
@@ -298,6 +343,60 @@ __global__ __launch_bounds__(BLK) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
+// WIDE consumer (round 4): the layers whose producing conv leaves more than SMALL_ROWS partial rows (levels 0-1: 432-1024 rows) used
+// to pay a finalize launch between the conv and this pass (a 5 us link of the dependent chain, 12 of them per forward).  Here the
+// pass runs as <= 2 workgroups of 1024 threads per CU: every workgroup finishes the rows itself (rows_sum_wide; the rows come out of
+// the L2 <= 512 times instead of once per 256-thread workgroup), with the loads of its first two rows already in flight, and
+// workgroup 0 publishes stat[4][C] / the running statistics like the small route does.
+constexpr int WNT = 1024;
+constexpr int WIDE_ROWS = 1024;
+// bf16 only (the plan takes this route in the bf16 path).  WPRE rows per thread are requested BEFORE the prologue (raw 16-byte
+// pieces, 4 VGPRs each): at level 1 that is the whole tensor, at level 0 more than half of it -- the statistics are finished
+// while the first loads are in flight, and the main loop keeps WPRE loads per thread in flight.
+constexpr int WPRE = 8;
+__global__ __launch_bounds__(WNT) void bn_apply_wide_kernel(const bf16* __restrict__ y, int ycs, int C, int64_t M, int64_t V,
+                                                            float* __restrict__ stat, BnPart tr, const float* __restrict__ drop,
+                                                            bf16* __restrict__ z, int zcs) {
+    constexpr int VEC = 8;
+    const int G = C / VEC;
+    const int64_t gtid = (int64_t)blockIdx.x * WNT + threadIdx.x;
+    const int g = (int)(gtid % G);
+    int64_t row = gtid / G;
+    const int64_t rstep = ((int64_t)gridDim.x * WNT) / G;
+    bf16x8 raw[WPRE];
+#pragma unroll
+    for (int u = 0; u < WPRE; u++)
+        if (row + u * rstep < M) raw[u] = *reinterpret_cast<const bf16x8*>(y + (row + u * rstep) * ycs + g * VEC);
+    __shared__ double red[WNT * 4];
+    __shared__ float ab[2 * MAXC_BN];
+    bn_train_coeffs<WNT>(tr, C, stat, ab, red);
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { a[i] = ab[g * VEC + i]; b[i] = ab[MAXC_BN + g * VEC + i]; }
+    DropCache<VEC> dc;
+    while (row < M) {
+#pragma unroll
+        for (int u = 0; u < WPRE; u++) {
+            const int64_t r = row + u * rstep;
+            if (r < M) {
+                dc.at(drop, r, V, C, g * VEC);
+                bf16x8 o;
+#pragma unroll
+                for (int i = 0; i < VEC; i++) {
+                    float t = fmaf((float)raw[u][i], a[i], b[i]);
+                    t = t > 0.f ? t : 0.f;
+                    o[i] = (bf16)(t * dc.s[i]);
+                }
+                *reinterpret_cast<bf16x8*>(z + r * zcs + g * VEC) = o;
+            }
+        }
+        row += WPRE * rstep;
+#pragma unroll
+        for (int u = 0; u < WPRE; u++)
+            if (row + u * rstep < M) raw[u] = *reinterpret_cast<const bf16x8*>(y + (row + u * rstep) * ycs + g * VEC);
+    }
+}
+
 // Second half of an encoder block: the same apply pass, one thread per 2x2x2 pooling window and channel group — writes the
 // eight activated voxels (the skip tensor) AND their maximum (MaxPool3d(2,2), models/unet.py:40,71), so the pooling launch and
 // its re-read of the skip tensor disappear.  Even D, H, W only (every voxel lies in exactly one window).
@@ -370,6 +469,86 @@ __global__ __launch_bounds__(BLK) void bn_apply_pool_kernel(const T* __restrict_
             if (pc != 0) continue;
         }
         stv<T, VEC>(pl + ((((int64_t)n * Do + d_o) * Ho + ho) * Wo + wo) * pcs + g * VEC, m);
+    }
+}
+
+// The pooled pass as a wide consumer (bf16, two threads per window): two windows (8 pieces) per thread are requested before the
+// prologue finishes the statistics; same arithmetic per element as the kernel above.
+constexpr int WPW = 2;
+__global__ __launch_bounds__(WNT) void bn_apply_pool_wide_kernel(const bf16* __restrict__ y, int ycs, int C, int N, int D, int H, int W,
+                                                                 float* __restrict__ stat, BnPart tr, const float* __restrict__ drop,
+                                                                 bf16* __restrict__ z, int zcs, bf16* __restrict__ pl, int pcs) {
+    constexpr int VEC = 8;
+    const int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+    const unsigned gtid = blockIdx.x * WNT + threadIdx.x;
+    const int g = (int)(gtid % (unsigned)G);
+    const int pc = (int)((gtid / (unsigned)G) & 1u);
+    const unsigned TPW = (unsigned)G * 2u;
+    const unsigned windows = (unsigned)N * Do * Ho * Wo, wstep = (gridDim.x * WNT) / TPW;
+    unsigned win = gtid / TPW;
+    bf16x8 raw[WPW][4];
+    int base[WPW], smp[WPW];          // voxel index of the window's corner (+ this thread's x offset), its sample
+    auto issue = [&]() {
+#pragma unroll
+        for (int u = 0; u < WPW; u++) {
+            unsigned r = win + u * wstep;
+            if (r < windows) {
+                const int wo = (int)(r % (unsigned)Wo); r /= (unsigned)Wo;
+                const int ho = (int)(r % (unsigned)Ho); r /= (unsigned)Ho;
+                const int d_o = (int)(r % (unsigned)Do);
+                smp[u] = (int)(r / (unsigned)Do);
+                base[u] = ((smp[u] * D + 2 * d_o) * H + 2 * ho) * W + 2 * wo + pc;
+#pragma unroll
+                for (int q = 0; q < 4; q++)       // k = 2q + pc: (dz, dy) = (q >> 1, q & 1), dx = pc
+                    raw[u][q] = *reinterpret_cast<const bf16x8*>(y + (int64_t)(base[u] + ((q >> 1) * H + (q & 1)) * W) * ycs + g * VEC);
+            }
+        }
+    };
+    issue();
+    __shared__ double red[WNT * 4];
+    __shared__ float ab[2 * MAXC_BN];
+    bn_train_coeffs<WNT>(tr, C, stat, ab, red);
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) { a[i] = ab[g * VEC + i]; b[i] = ab[MAXC_BN + g * VEC + i]; }
+    float ds[VEC];
+    int dn = -1;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) ds[i] = 1.f;
+    while (win < windows) {
+#pragma unroll
+        for (int u = 0; u < WPW; u++) {
+            const unsigned w_ = win + u * wstep;
+            if (w_ < windows) {                                   // uniform over a window's thread pair (the lane swap below)
+                if (drop && smp[u] != dn) {
+                    dn = smp[u];
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) ds[i] = drop[(int64_t)dn * C + g * VEC + i];
+                }
+                float m[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; i++) m[i] = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int i = 0; i < VEC; i++) {
+                        float t = fmaf((float)raw[u][q][i], a[i], b[i]);
+                        t = t > 0.f ? t : 0.f;
+                        o[i] = (bf16)(t * ds[i]);
+                        const float of = (float)o[i];              // the pooled value is the maximum of the STORED values
+                        m[i] = of > m[i] ? of : m[i];
+                    }
+                    *reinterpret_cast<bf16x8*>(z + (int64_t)(base[u] + ((q >> 1) * H + (q & 1)) * W) * zcs + g * VEC) = o;
+                }
+                bf16x8 mo;
+#pragma unroll
+                for (int i = 0; i < VEC; i++) { float om = __shfl_xor(m[i], G, 64); mo[i] = (bf16)(om > m[i] ? om : m[i]); }
+                if (pc == 0) *reinterpret_cast<bf16x8*>(pl + (int64_t)w_ * pcs + g * VEC) = mo;
+            }
+        }
+        win += WPW * wstep;
+        issue();
     }
 }
 
@@ -599,6 +778,20 @@ inline bool bn_small(int C, int64_t M) {
 inline int bn_small_rows(int nblk, int C) { return nblk > SMALL_ROWS ? SMALL_ROWS : nblk; }
 bool bn_small_ok(int C, int64_t M, int rows) { return bn_small(C, M) && rows >= 1 && rows <= SMALL_ROWS; }
 bool bn_small_route(int C, int64_t M) { return bn_small(C, M); }
+// round 4: `rows` partial rows written by a conv epilogue ([rows][2][C]) can be finished by the consumer (thin workgroups up to
+// SMALL_ROWS rows, the wide kernels above that): no finalize launch between the conv and the apply pass
+inline bool wide_shape_ok(int C) { return C >= 8 && C <= MAXC_BN && (C & (C - 1)) == 0; }
+bool bn_rows_route_ok(int C, int64_t M, int rows) {
+    const int mode = mi3d_routes().wide_bn;
+    if (!(mode & 1) || rows < 1 || M * C >= (1ll << 31)) return false;
+    if (rows <= SMALL_ROWS && rows < mi3d_routes().wide_min_rows) return C >= 4 && C <= MAXC_BN && (C & (C - 1)) == 0;
+    return (mode & 2) && rows <= WIDE_ROWS && wide_shape_ok(C) && (int64_t)rows * C <= (int64_t)WIDE_J * WNT * 2;
+}
+inline int wide_grid(int64_t total_threads) {
+    int want = (int)((total_threads + WNT - 1) / WNT), cap = mi3d_routes().wide_bn_wgs;
+    if (cap < 1) cap = 1;
+    return want < 1 ? 1 : (want > cap ? cap : want);
+}
 
 int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* stat,
@@ -646,13 +839,21 @@ int bn_apply_relu_drop(int dtype, const void* y, int ycs, int C, int64_t M, int6
     MI3D_CHECK_ARG(!drop || M < (1ll << 32), "bn_apply: dropout path needs M < 2^32 (32-bit sample index)");
     BnPart t{};
     if (small) {
-        MI3D_CHECK_ARG(small->part && small->nrows >= 1 && small->nrows <= SMALL_ROWS && C <= MAXC_BN && small->gamma && small->beta,
+        MI3D_CHECK_ARG(small->part && small->nrows >= 1 && small->nrows <= WIDE_ROWS && C <= MAXC_BN && small->gamma && small->beta,
                        "bn_apply: bad partial statistics");
         t = BnPart{small->part, small->nrows, M, small->gamma, small->beta, small->running_mean, small->running_var,
                    small->num_batches_tracked, small->momentum, small->eps};
     }
     DISPATCH_T(dtype, T, {
         bool v8 = vec8_ok(C, ycs, zcs, y, z, sizeof(T));
+        if (small && (small->nrows > SMALL_ROWS || small->nrows >= mi3d_routes().wide_min_rows)) {
+            if (v8 && dtype == MI3D_BF16 && wide_shape_ok(C) && (int64_t)small->nrows * C <= (int64_t)WIDE_J * WNT * 2) {
+                bn_apply_wide_kernel<<<wide_grid(M * (C / 8)), WNT, 0, s>>>((const bf16*)y, ycs, C, M, V, stat, t, drop, (bf16*)z, zcs);
+                MI3D_LAUNCH_CHECK();
+                return 0;
+            }
+            MI3D_CHECK_ARG(small->nrows <= SMALL_ROWS, "bn_apply: %d partial rows need the wide kernel (C = %d, 16-byte rows)", small->nrows, C);
+        }
         int grid = v8 ? stream_grid(M * (C / 8), C / 8) : stream_grid(M * C, C);
         if (v8 && small) bn_apply_kernel<T, 8, true><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
         else if (v8) bn_apply_kernel<T, 8, false><<<grid, BLK, 0, s>>>((const T*)y, ycs, C, M, V, stat, t, drop, (T*)z, zcs);
@@ -670,7 +871,7 @@ int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, flo
                    "bn_apply_pool: needs even sides and fewer than 2^31 elements");
     BnPart t{};
     if (small) {
-        MI3D_CHECK_ARG(small->part && small->nrows >= 1 && small->nrows <= SMALL_ROWS && C <= MAXC_BN && small->gamma && small->beta,
+        MI3D_CHECK_ARG(small->part && small->nrows >= 1 && small->nrows <= WIDE_ROWS && C <= MAXC_BN && small->gamma && small->beta,
                        "bn_apply_pool: bad partial statistics");
         t = BnPart{small->part, small->nrows, M, small->gamma, small->beta, small->running_mean, small->running_var,
                    small->num_batches_tracked, small->momentum, small->eps};
@@ -682,6 +883,14 @@ int bn_apply_relu_drop_pool(int dtype, const void* y, int ycs, int C, Geo g, flo
         const int G8 = C / 8;
         const bool pair = v8 && (G8 & (G8 - 1)) == 0 && G8 <= 32 && !mi3d_routes().no_pool_pair;
         if (pair) grid = stream_grid(M / 8 * G8 * 2, G8 * 2);
+        if (small && (small->nrows > SMALL_ROWS || small->nrows >= mi3d_routes().wide_min_rows)) {
+            if (pair && dtype == MI3D_BF16 && wide_shape_ok(C) && (int64_t)small->nrows * C <= (int64_t)WIDE_J * WNT * 2) {
+                bn_apply_pool_wide_kernel<<<wide_grid(M / 8 * G8 * 2), WNT, 0, s>>>((const bf16*)y, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, (bf16*)z, zcs, (bf16*)pooled, pcs);
+                MI3D_LAUNCH_CHECK();
+                return 0;
+            }
+            MI3D_CHECK_ARG(small->nrows <= SMALL_ROWS, "bn_apply_pool: %d partial rows need the wide kernel (C = %d)", small->nrows, C);
+        }
         if (pair && small) bn_apply_pool_kernel<T, 8, true, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
         else if (pair) bn_apply_pool_kernel<T, 8, false, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);
         else if (v8 && small) bn_apply_pool_kernel<T, 8, true><<<grid, BLK, 0, s>>>(yp, ycs, C, g.N, g.D, g.H, g.W, stat, t, drop, zp, zcs, pp, pcs);

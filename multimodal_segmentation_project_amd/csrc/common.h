@@ -76,6 +76,9 @@ void mi3d_set_error(const char* fmt, ...);
     X(no_wgrad_xcd, 0)      /* 1: full-resolution weight gradients take tile = slab index (rounds 1-3) instead of XCD-contiguous tiles */ \
     X(no_upbwd_xcd_mix, 0)  /* 1: fused transposed-conv backward with the round-3 block mapping (even blocks weight gradient, odd data gradient: one kind per XCD) */ \
     X(opt_tail, 0)          /* 1: AdamW + weight re-pack of everything but the leading encoder blocks on the aux stream beside the end of the backward (TrainStep reads it; measured neutral: the aux stream is the long pole there) */ \
+    X(wide_bn, 3)           /* round 4: the conv epilogue's BatchNorm partial rows are finished by the apply pass itself, no finalize launch: 1 = layers with <= 128 rows (level 2; every thin workgroup's prologue), 2 = also the layers with up to 1024 rows (levels 0-1) through wide_bn_wgs workgroups of 1024 threads; 0 = a finalize launch per layer (rounds 1-3) */ \
+    X(wide_bn_wgs, 256)     /* workgroups of a wide BatchNorm pass */ \
+    X(wide_min_rows, 129)   /* partial rows from which the wide kernel (instead of the thin workgroups' prologue) finishes the statistics */ \
     X(conv_dma, 0)          /* MI3D_EXPERIMENTS builds only: LDS-DMA staging in the Cout = 16 persistent forward conv */
 struct Mi3dRoutes {
 #define MI3D_ROUTE_FIELD(name, dflt) int name = dflt;

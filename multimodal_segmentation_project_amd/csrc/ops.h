@@ -121,6 +121,10 @@ int bn_train_stats(int dtype, const void* y, int ycs, int C, int64_t M, const fl
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                    float eps, float* stat, float* ws, hipStream_t s, int* small_rows = nullptr);
 bool bn_small_ok(int C, int64_t M, int rows);       // a producer's `rows` partial rows can take the consumer-prologue route
+// round 4: the `rows` partial rows of a conv epilogue can be handed to bn_apply_relu_drop(_pool) as a BnSmall (no finalize launch):
+// <= 128 rows by the thin kernels' prologue, up to 1024 rows by the wide (1024-thread) kernels; needs C a power of two, 8..256,
+// 16-byte aligned channels-last rows, and for the pooled pass the two-threads-per-window shape
+bool bn_rows_route_ok(int C, int64_t M, int rows);
 struct BnSmall {
     const float* part; int nrows;
     const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* num_batches_tracked;

@@ -330,9 +330,18 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
                                       H.Cout, g, c.s));
         }
         int small_rows = 0;      // deep levels: the statistics' few partial rows are finished by the apply kernel (no finalize launch)
+        const float* rows_at = c.at<float>(p.bnws);
         if (fused_stats) {
-            MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g), H.Cout, g.M(), c.P(H.pidx + 2),
-                                       c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps, c.at<float>(H.stat), c.s));
+            // round 4: the apply pass finishes the conv epilogue's partial rows itself (bn.hip, wide consumer); the pooled pass only
+            // in its two-threads-per-window form
+            const int rows = c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g);
+            const bool pool_pass = h == 1 && pooled;
+            if (p.dt == MI3D_BF16 && bn_rows_route_ok(H.Cout, g.M(), rows) && !(pool_pass && mi3d_routes().no_pool_pair)) {
+                small_rows = rows;
+                rows_at = c.at<float>(p.statpart);
+            } else
+                MI3D_TRY(bn_train_finalize(c.at<float>(p.statpart), rows, H.Cout, g.M(), c.P(H.pidx + 2),
+                                           c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps, c.at<float>(H.stat), c.s));
         } else if (training && ksd > 0) {
             MI3D_TRY(bn_train_stats_splitk(c.at<float>(p.skws), ksd, c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g.M(), c.P(H.pidx + 2),
                                            c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps, c.at<float>(H.stat),
@@ -344,8 +353,8 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             MI3D_CHECK_ARG(rm && rv, "eval-mode forward needs running statistics");
             MI3D_TRY(bn_eval_stats(H.Cout, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, p.d.bn_eps, c.at<float>(H.stat), c.s));
         }
-        BnSmall sm{c.at<float>(p.bnws), small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps};
-        if (h == 0 && training && small_rows > 0 && p.dt == MI3D_BF16 && B.h[1].mfma && mi3d_routes().apply_on_load &&
+        BnSmall sm{rows_at, small_rows, c.P(H.pidx + 2), c.P(H.pidx + 3), rm, rv, nbt, mom, p.d.bn_eps};
+        if (h == 0 && training && small_rows > 0 && !fused_stats && p.dt == MI3D_BF16 && B.h[1].mfma && mi3d_routes().apply_on_load &&
             conv3_mfma_xform_ok(B.h[1].Cin, B.h[1].Cout, g)) {
             // no apply launch: conv1 finishes the statistics rows in its prologue, applies while staging and writes z1 on the way
             xfa.mode = 1;

@@ -60,6 +60,15 @@ def _priority_stream(device, cls):
 
 
 _STREAM_CACHE = {}      # (device index, priority, role) -> stream chosen by concurrent_stream
+_CAPTURE_STREAMS = {}   # device index -> the stream hipGraph captures run on (nothing else ever does)
+
+
+def _capture_stream(device):
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _CAPTURE_STREAMS:
+        _CAPTURE_STREAMS[key] = _priority_stream(dev, 0)
+    return _CAPTURE_STREAMS[key]
 
 
 def concurrent_stream(device, candidates=6, hold_us=300, priority="high", role="aux"):
@@ -319,21 +328,28 @@ class _StepBase:
             for t, c in zip(state, snap):
                 t.copy_(c)
             s.synchronize()
-
+        # The capture itself runs on a PRIVATE stream that never carries a collective.  The warm-up above issued the last bucket's
+        # all-reduce on `s` (and torch hands out `s` from a pool other step objects' exchange streams come from): the process
+        # group's watchdog thread polls the end events of such work for up to its 100 ms period, and a poll that meets a stream
+        # in capture ends the capture with hipErrorCapturedEvent (seen once in ~10 runs of the forced-exchange test).
+        cs = _capture_stream(self.device)
+        cs.wait_stream(s)
+        with torch.cuda.stream(cs):
             def cut(fn):
                 g = C.c_void_p()
-                call("mi3d_graph_end", s.cuda_stream, C.byref(g))
+                call("mi3d_graph_end", cs.cuda_stream, C.byref(g))
                 segs.append((g, fn))
-                call("mi3d_graph_begin", s.cuda_stream)
+                call("mi3d_graph_begin", cs.cuda_stream)
 
-            call("mi3d_graph_begin", s.cuda_stream)
+            call("mi3d_graph_begin", cs.cuda_stream)
             try:
                 self._enqueue(st, variant, cut)
             finally:
                 g = C.c_void_p()
-                call("mi3d_graph_end", s.cuda_stream, C.byref(g))
+                call("mi3d_graph_end", cs.cuda_stream, C.byref(g))
                 segs.append((g, None))
         torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.current_stream().wait_stream(cs)
         return segs
 
 

@@ -170,3 +170,37 @@ def test_optimizer_tail_on_the_aux_stream_is_bitwise_the_serial_tail(routes, siz
     assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1) and torch.equal(s0, s1)
     for a, b in zip(b0, b1):
         assert torch.equal(a, b)
+
+
+def test_wide_batchnorm_consumers_with_dropout_masks(routes):
+    """Round 4: at levels 0-1 the BatchNorm apply (+ pool) passes finish the conv epilogue's partial rows themselves, as <= 256
+    workgroups of 1024 threads (bn_apply_wide_kernel / bn_apply_pool_wide_kernel), instead of a finalize launch per layer
+    (models/unet.py:12-14,16-18).  64^3 N=2 with Dropout3d(p = 0.3): 512 rows at level 0 (persistent convs) and 128 / 432-row
+    layers below; against the finalize route the statistics are the same rows summed in double in another order, so the BatchNorm
+    buffers agree to fp32 roundoff and everything downstream to bf16 re-rounding noise -- a wrong sample's dropout scale, a wrong
+    window or a wrong coefficient would move the loss by percents."""
+    x, y = synth(2, 64, 779, blocky=True)
+    res = []
+    for mode in (3, 0):
+        routes.set("wide_bn", mode)
+        torch.manual_seed(0)            # also the seed of the model's counter-based dropout stream: the same masks on both routes
+        m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.3).to(DEV).train()
+        ts = TrainStep(m, loss="combined", lr=0.0, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=False)
+        ts.load_batch(x.to(DEV), y.to(DEV))
+        out = ts.step_static().clone()
+        torch.cuda.synchronize()
+        res.append((out.cpu(), ts.arena.g.clone().cpu(), {k: b.clone().cpu() for k, b in m.named_buffers()}))
+        ts.close()
+    routes.reset("wide_bn")
+    (o0, g0, b0), (o1, g1, b1) = res
+    assert abs(float(o0[0]) - float(o1[0])) < 2e-3 * abs(float(o1[0])), (o0, o1)
+    assert (o0[1:] - o1[1:]).abs().max() < 2e-3, (o0, o1)
+    # the first layer's statistics see identical inputs on both routes: equal to fp32 roundoff; deeper layers inherit bf16 re-rounding
+    for k in b0:
+        if "num_batches_tracked" in k:
+            assert torch.equal(b0[k], b1[k]), k
+        elif k.startswith("encoder.0.double_conv.1."):
+            assert relerr(b0[k], b1[k]) < 1e-6, (k, relerr(b0[k], b1[k]))
+        else:
+            assert relerr(b0[k], b1[k]) < 5e-3, (k, relerr(b0[k], b1[k]))
+    assert relerr(g0, g1) < 5e-2, relerr(g0, g1)
