@@ -145,6 +145,11 @@ int mi3d_event_destroy(void* event);
  * offers high / normal; the aux stream of the deferred weight gradients wants the LOWEST class, so that the wave dispatcher
  * gives a free workgroup slot to the data-gradient chain first.  The caller owns the stream (mi3d_stream_destroy). */
 int mi3d_stream_create(int priority_class, void** stream_out);
+/* A non-blocking hipStream_t whose kernels may only run on `cus_per_xcd` (1..31) of the 32 compute units of every XCD
+ * (hipExtStreamCreateWithCUMask; mask bit i = CU i / 8 of XCD i % 8, measured with tools/micro/cu_mask_probe.hip): from_top = 0
+ * takes CUs 0..n-1 of each XCD, 1 the last n.  Round 4: a CU partition for the aux stream of the deferred weight gradients, so
+ * that they stop taking workgroup slots from the data-gradient chain on every CU. */
+int mi3d_stream_create_masked(int cus_per_xcd, int from_top, void** stream_out);
 int mi3d_stream_destroy(void* stream);
 /* Route switches: every kernel-selection switch of the library ("no_persist", "no_fused_bwd", "ks_target", ... -- the table
  * in INTEGRATION.md) is read from the environment (MI3D_<NAME>=<int>) ONCE, when the library is first used; afterwards only

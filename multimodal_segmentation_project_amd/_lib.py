@@ -65,6 +65,7 @@ _SIGS = {
     "mi3d_event_create": (i32, [C.POINTER(vp)]),
     "mi3d_event_destroy": (i32, [vp]),
     "mi3d_stream_create": (i32, [i32, C.POINTER(vp)]),
+    "mi3d_stream_create_masked": (i32, [i32, i32, C.POINTER(vp)]),
     "mi3d_stream_destroy": (i32, [vp]),
     "mi3d_debug_set_route": (i32, [C.c_char_p, i32]),
     "mi3d_debug_get_route": (i32, [C.c_char_p, C.POINTER(C.c_int)]),

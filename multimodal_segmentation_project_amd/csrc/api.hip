@@ -377,6 +377,21 @@ int mi3d_stream_create(int priority_class, void** stream_out) {
     *stream_out = (void*)s;
     return 0;
 }
+int mi3d_stream_create_masked(int cus_per_xcd, int from_top, void** stream_out) {
+    MI3D_CHECK_ARG(stream_out && cus_per_xcd >= 1 && cus_per_xcd <= 31, "mi3d_stream_create_masked: bad arguments");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    MI3D_HIP(hipGetDevice(&dev));
+    MI3D_HIP(hipGetDeviceProperties(&prop, dev));
+    MI3D_CHECK_ARG(prop.multiProcessorCount == 256, "mi3d_stream_create_masked: expects 8 XCDs x 32 CUs, device has %d CUs", prop.multiProcessorCount);
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lo = from_top ? (32 - cus_per_xcd) * 8 : 0, hi = lo + cus_per_xcd * 8;
+    for (int b = lo; b < hi; b++) mask[b >> 5] |= 1u << (b & 31);
+    hipStream_t s;
+    MI3D_HIP(hipExtStreamCreateWithCUMask(&s, 8, mask));
+    *stream_out = (void*)s;
+    return 0;
+}
 int mi3d_stream_destroy(void* stream) {
     if (stream) MI3D_HIP(hipStreamDestroy((hipStream_t)stream));
     return 0;

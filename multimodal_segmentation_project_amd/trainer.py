@@ -71,7 +71,17 @@ def _capture_stream(device):
     return _CAPTURE_STREAMS[key]
 
 
-def concurrent_stream(device, candidates=6, hold_us=300, priority="high", role="aux"):
+def _masked_stream(device, cus_per_xcd, from_top=1):
+    """torch stream object around a hipStream_t confined to cus_per_xcd CUs of every XCD (mi3d_stream_create_masked)."""
+    h = C.c_void_p()
+    call("mi3d_stream_create_masked", int(cus_per_xcd), int(from_top), C.byref(h))
+    st = torch.cuda.ExternalStream(h.value, device=device)
+    st.mi3d_handle = h
+    st.mi3d_cus_per_xcd = int(cus_per_xcd)
+    return st
+
+
+def concurrent_stream(device, candidates=6, hold_us=300, priority="high", role="aux", cus_per_xcd=0):
     """A stream whose kernels really run BESIDE those of the current (compute) stream.  HIP multiplexes streams onto a few
     hardware queues, and two streams that share a queue execute strictly one after the other (measured with rocprofv3: the
     default stream and the 8th stream created in a process both sat on queue 4, and a collective kernel on the latter ran
@@ -84,14 +94,16 @@ def concurrent_stream(device, candidates=6, hold_us=300, priority="high", role="
     RuntimeWarning: the step is still correct, only nothing will run beside the compute stream."""
     import warnings
     dev = torch.device(device)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), priority, role)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), priority, role, int(cus_per_xcd))
     if key in _STREAM_CACHE:
         return _STREAM_CACHE[key]
     main = torch.cuda.current_stream(device)
     buf = torch.zeros(1024, dtype=torch.float32, device=device)
     best = None
     for i in range(candidates):
-        if i == 0 and priority == "low":
+        if i == 0 and cus_per_xcd > 0:
+            c = _masked_stream(device, cus_per_xcd)
+        elif i == 0 and priority == "low":
             c = _priority_stream(device, +1)
         elif i == 0 and priority == "high":
             c = torch.cuda.Stream(device=device, priority=-1)
@@ -357,7 +369,7 @@ class TrainStep(_StepBase):
     def __init__(self, model, loss="combined", lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8,
                  grad_accum=1, kd_teacher=None, kd_alpha=0.7, kd_temperature=2.0, process_group=None,
                  compute_dtype=None, use_graph=False, aux_wgrad=None, reference_zero_grad_quirk=False,
-                 force_comm=False, overlap_teacher=True, keep_logits=False):
+                 force_comm=False, overlap_teacher=True, keep_logits=False, aux_cus=None):
         """aux_wgrad: the backward's critical path is the input-gradient chain alone -- the weight gradients of the decoder's
         full-resolution convs and of all deep-level convs run on a second stream (include/mi3d.h, mi3d_unet_backward: aux_stream),
         forked from the chain at most three times and joined in front of the optimizer; bit-identical results.  None (default):
@@ -394,7 +406,9 @@ class TrainStep(_StepBase):
             # finish ~150 us before the end of the backward, so the big all-reduce bucket (dp.bucket_ranges) would lose the
             # 0.45 ms of encoder backward it hides under; the exchange is worth more than the ~20 us the deferral buys
             aux_wgrad = not use_graph and not self.do_comm
-        self.aux_stream = (concurrent_stream(self.device, priority=os.environ.get("MI3D_AUX_PRIO", "high")) if aux_wgrad else None)
+        self.aux_stream = (concurrent_stream(self.device, priority=os.environ.get("MI3D_AUX_PRIO", "high"),
+                                             cus_per_xcd=int(aux_cus if aux_cus is not None else os.environ.get("MI3D_AUX_CUS", "0")))
+                           if aux_wgrad else None)
         self._events = None
         self._event_handles = []
         if aux_wgrad:

@@ -28,14 +28,25 @@ def main():
         cfgs.append((name, {r.split(":")[0]: int(r.split(":")[1]) for r in rs.split(",") if r}))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if "--pool-main" in sys.argv:      # the step on a non-null stream (a CU-masked aux stream is a BLOCKING stream: it serialises with the null stream)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     torch.manual_seed(0)
-    model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).train()
-    ts = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=False,
-                   aux_wgrad=("--no-aux" not in sys.argv))
     x, y = bench.synth(batch, size, 1234)
-    ts.load_batch(x.to(dev), y.to(dev))
+    steps_by_cus = {}
 
-    def run():
+    def step_for(cus):      # "aux_cus:N" is not a route: the aux stream is confined to N CUs per XCD (its own TrainStep object)
+        if cus not in steps_by_cus:
+            torch.manual_seed(0)
+            model = mi.UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(dev).train()
+            t = TrainStep(model, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=False,
+                          aux_wgrad=("--no-aux" not in sys.argv), aux_cus=cus)
+            t.load_batch(x.to(dev), y.to(dev))
+            steps_by_cus[cus] = t
+        return steps_by_cus[cus]
+
+    ts = step_for(0)
+
+    def run(ts=ts):
         for _ in range(3):
             ts.step_static()
         torch.cuda.synchronize()
@@ -48,10 +59,12 @@ def main():
     res = {n: [] for n, _ in cfgs}
     for _ in range(rounds):
         for name, routes in cfgs:
+            routes = dict(routes)
+            t = step_for(routes.pop("aux_cus", 0))
             saved = {k: _lib.get_route(k) for k in routes}
             for k, v in routes.items():
                 _lib.set_route(k, v)
-            res[name].append(run())
+            res[name].append(run(t))
             for k, v in saved.items():
                 _lib.set_route(k, v)
     for name, _ in cfgs:
