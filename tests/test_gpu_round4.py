@@ -204,3 +204,28 @@ def test_wide_batchnorm_consumers_with_dropout_masks(routes):
         else:
             assert relerr(b0[k], b1[k]) < 5e-3, (k, relerr(b0[k], b1[k]))
     assert relerr(g0, g1) < 5e-2, relerr(g0, g1)
+
+
+def test_cu_masked_aux_stream_is_bitwise_the_unmasked_one():
+    """mi3d_stream_create_masked (hipExtStreamCreateWithCUMask): the aux stream of the deferred weight gradients confined to 16 of
+    the 32 CUs of every XCD.  A masked stream is a BLOCKING stream (it serialises with the null stream), so the step runs on a
+    pool stream here; where the weight gradients run changes nothing in what they compute."""
+    x, y = synth(2, 48, 781, blocky=True)
+    res = []
+    with torch.cuda.stream(torch.cuda.Stream(device=DEV)):
+        for cus in (0, 16):
+            torch.manual_seed(0)
+            m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+            ts = TrainStep(m, loss="combined", lr=1e-3, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=False, aux_cus=cus)
+            assert ts.aux_stream is not None
+            if cus:
+                assert getattr(ts.aux_stream, "mi3d_cus_per_xcd", 0) == cus and ts.aux_stream.mi3d_concurrent
+            ts.load_batch(x.to(DEV), y.to(DEV))
+            outs = [ts.step_static().clone() for _ in range(2)]
+            torch.cuda.synchronize()
+            res.append((outs, ts.arena.g.clone(), ts.arena.p.clone()))
+            ts.close()
+    (o0, g0, p0), (o1, g1, p1) = res
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)
