@@ -74,6 +74,8 @@ int64_t mi3d_unet_dropout_count(const mi3d_unet_desc* d);
  * publishes (batch mean, unbiased batch variance); mi3d_unet_bn_apply_deferred applies them to the real buffers later.  For
  * two forwards of ONE model on two streams (train_dann.py:268-272: source then target): the second one's updates of the
  * shared buffers are applied after both have run, in the reference's order, bit-identically to the serial execution.
+ * training | 4 (with 1 or 2): another forward runs beside this one on a second stream -- the BatchNorm apply passes stay thin
+ * (a finalize launch per layer at levels 0-1) instead of the wide whole-CU consumers, which slow each other down there.
  * drop_scales: device float[mi3d_unet_dropout_count] holding 0 or 1/(1-p), or NULL (p = 0 / eval).
  * logits: device float (N,out_channels,D,H,W), or NULL: the 1x1x1 head is not run (DANN target pass, whose logits nobody reads;
  * or the caller runs head + loss with mi3d_unet_head_loss_forward).  gap_out: device float (N, 2*features[L-1]) or NULL

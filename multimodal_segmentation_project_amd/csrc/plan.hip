@@ -230,6 +230,9 @@ struct Ctx {
     mutable int ndq = 0, nfork = 0;
     mutable bool aux_used = false;
     mutable bool packed = false;      // weight packs already done by the one-launch pack_all
+    // training & 4: another forward runs beside this one on a second stream (DANN source || target): the wide BatchNorm consumers
+    // (whole-CU 1024-thread workgroups) get in each other's way there (+45 us/step measured); thin consumers + finalize launches
+    mutable bool beside = false;
     // one pending weight-gradient slab sum: it rides in the next BatchNorm-backward reduction launch (or is flushed
     // with its own launch when another one arrives first / at the end of the call)
     mutable SlabJob pend;
@@ -336,7 +339,8 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             // in its two-threads-per-window form
             const int rows = c1_blocks ? c1_blocks : conv3_mfma_stat_blocks(H.Cin, H.Cout, g);
             const bool pool_pass = h == 1 && pooled;
-            if (p.dt == MI3D_BF16 && bn_rows_route_ok(H.Cout, g.M(), rows) && !(pool_pass && mi3d_routes().no_pool_pair)) {
+            if (p.dt == MI3D_BF16 && bn_rows_route_ok(H.Cout, g.M(), rows) && !(pool_pass && mi3d_routes().no_pool_pair) &&
+                !(c.beside && !bn_small_ok(H.Cout, g.M(), rows))) {
                 small_rows = rows;
                 rows_at = c.at<float>(p.statpart);
             } else
@@ -696,6 +700,8 @@ static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void
     MI3D_CHECK_ARG(workspace_bytes >= p.total, "workspace too small: %zu < %zu", workspace_bytes, p.total);
     MI3D_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     Ctx c{p, (char*)workspace, params, (hipStream_t)stream};
+    c.beside = (training & 4) != 0;
+    training &= 3;
     int L = p.L;
     if (d->in_channels > 1)
         MI3D_TRY(ncdhw_to_ndhwc(p.dt, x, c.at(p.xcl), d->in_channels, d->in_channels, d->N, p.geo[0].V(), c.s));

@@ -935,21 +935,23 @@ class DannStep(_StepBase):
         if fs is not None:
             fs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(fs):
-                call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab_side"], ptr(drop_t), 2,
+                call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab_side"], ptr(drop_t), 2 | 4,
                      None, feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], fs.cuda_stream)
         fused = st["fused_head"]
+        beside = 4       # two forwards side by side: thin BatchNorm consumers (include/mi3d.h); also in the serial order, so that
+        #                  both orders run the same kernels and stay bitwise equal
         if fused:       # source head + loss + metrics in one pass, logits never written (mi3d_unet_forward_loss)
-            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1, ptr(st["y"]), None,
+            call("mi3d_unet_forward_loss", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1 | beside, ptr(st["y"]), None,
                  C.byref(self.cfg), ptr(st["metrics"]), ptr(st["coef"]), ptr(st["metrics"][1:]), ptr(st["loss_ws"]),
                  ptr(st["met_ws"]), None, feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
         else:
-            call("mi3d_unet_forward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1,
+            call("mi3d_unet_forward", C.byref(desc), ptr(st["xs"]), st["ptab"], st["btab"], ptr(drop_s), 1 | beside,
                  ptr(st["logits"]), feat.data_ptr(), ptr(st["ws_s"]), st["ws_bytes"], s)
         if fs is not None:
             torch.cuda.current_stream().wait_stream(fs)
             call("mi3d_unet_bn_apply_deferred", C.byref(desc), st["btab"], st["btab_side"], s)
         else:
-            call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab"], ptr(drop_t), 1,
+            call("mi3d_unet_forward", C.byref(desc), ptr(st["xt"]), st["ptab"], st["btab"], ptr(drop_t), 1 | beside,
                  None, feat.data_ptr() + 4 * n * F, ptr(st["ws_t"]), st["ws_bytes"], s)      # the target logits are never read
         if not fused:
             call("mi3d_seg_loss_metrics_forward", ptr(st["logits"]), ptr(st["y"]), None, n, c, desc.D, v,

@@ -20,6 +20,7 @@ run --steps 40 --force-comm
 run --steps 40 --force-comm --graph-segments
 run --steps 40 --dtype fp32 --steps 10
 } 2>&1 | tee gpurun_out/r4_shapes.log
+[ -n "$SKIP_CONSTANTS" ] && exit 0
 {
 for shp in "--size 96 --batch 4" "--size 128 --batch 2" "--size 192 --batch 1"; do
   echo "# constants at: $shp (default 128 / 128 / 288)"
