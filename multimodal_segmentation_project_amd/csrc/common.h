@@ -79,6 +79,7 @@ void mi3d_set_error(const char* fmt, ...);
     X(wide_bn, 3)           /* round 4: the conv epilogue's BatchNorm partial rows are finished by the apply pass itself, no finalize launch: 1 = layers with <= 128 rows (level 2; every thin workgroup's prologue), 2 = also the layers with up to 1024 rows (levels 0-1) through wide_bn_wgs workgroups of 1024 threads; 0 = a finalize launch per layer (rounds 1-3) */ \
     X(wide_bn_wgs, 256)     /* workgroups of a wide BatchNorm pass */ \
     X(wide_min_rows, 129)   /* partial rows from which the wide kernel (instead of the thin workgroups' prologue) finishes the statistics */ \
+    X(splitk_ticket, 1)     /* round 4: a split-K forward conv of a training step finishes itself (the last of a tile's ks workgroups sums the partials, stores y and the BatchNorm partial row); 0 = the bn_stats_splitk launch does (rounds 2-3) */ \
     X(conv_dma, 0)          /* MI3D_EXPERIMENTS builds only: LDS-DMA staging in the Cout = 16 persistent forward conv */
 struct Mi3dRoutes {
 #define MI3D_ROUTE_FIELD(name, dflt) int name = dflt;

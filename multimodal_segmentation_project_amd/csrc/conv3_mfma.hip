@@ -74,6 +74,8 @@ __global__ void pack_mfma_kernel(const float* __restrict__ w, int Cin, int Cout,
 constexpr int PK_LD = 16 * 27 + 1;
 __global__ __launch_bounds__(BLK) void pack_all_kernel(PackJobs J) {
     __shared__ float wl[16 * PK_LD];
+    if (blockIdx.x == 0 && J.zero)
+        for (int i = threadIdx.x; i < J.nzero; i += BLK) J.zero[i] = 0;
     int b = blockIdx.x, ji = 0;
     while (ji + 1 < J.n && b >= J.j[ji + 1].blk0) ji++;
     const float* __restrict__ w = J.j[ji].w;
@@ -414,7 +416,7 @@ constexpr size_t CONV8_XF_LDS = 256 * 6 * sizeof(float);     // XF coefficient t
 // channel chunks they own.  Output group 0 also WRITES the transformed tensor for the voxels inside its tile (xf.side): the
 // weight-gradient kernels of the backward read it (z1 resp. dy) exactly as before.  Element for element the arithmetic is
 // bn_apply_kernel's / bn_bwd_apply_kernel's (same fmaf order, same rounding), so both routes give the same bits.
-template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK, int XF = 0>
+template <int TZ, int TYB, int TXB, int BX, int COB, bool STATS, bool SPLITK, int XF = 0, bool TK = false>
 __global__ __launch_bounds__(512, XF == 2 ? 2 : 4) void conv3_mfma8_kernel(const bf16* __restrict__ x, int xcs, int Cin,
                                                           const bf16* __restrict__ wp, const float* __restrict__ bias,
                                                           bf16* __restrict__ y, int ycs, int CoutTotal, int D, int H, int W,
@@ -438,6 +440,7 @@ __global__ __launch_bounds__(512, XF == 2 ? 2 : 4) void conv3_mfma8_kernel(const
     float (*red)[COB][16][2] = reinterpret_cast<float (*)[COB][16][2]>(lds8 + (NVOXP * 16 + 14 * COB * 512) * 2);
     Bid bid_ = real_bid();
     int tile = xcd_contig(bid_.x, bid_.gx);
+    [[maybe_unused]] const int tile_id = tile;
     int tx_ = tile % tilesX; tile /= tilesX;
     int ty_ = tile % tilesY; tile /= tilesY;
     int tz_ = tile % tilesZ; int n = tile / tilesZ;
@@ -660,10 +663,100 @@ __global__ __launch_bounds__(512, XF == 2 ? 2 : 4) void conv3_mfma8_kernel(const
             if (gz < D && gy < H && gx < W) {
                 float* pp = pk + ((((int64_t)n * D + gz) * H + gy) * W + gx) * CoutTotal + cobBase * 16 + g * 4;
 #pragma unroll
-                for (int c = 0; c < COB; c++) *reinterpret_cast<f32x4*>(pp + c * 16) = acc[r][c];
+                for (int c = 0; c < COB; c++) {
+                    if constexpr (TK) {          // write-through (agent-coherent) store: the finishing workgroup sits on another XCD
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(pp + c * 16), "v"(acc[r][c]) : "memory");
+                    } else
+                        *reinterpret_cast<f32x4*>(pp + c * 16) = acc[r][c];
+                }
             }
         }
-        return;
+        if constexpr (!TK) return;
+        else {
+            // ---- split-K ticket: the last of this (tile, output group)'s ks workgroups finishes the tile.  Release the partials
+            // (agent scope: the other workgroups sit on other XCDs), take a ticket on a counter only these ks workgroups touch,
+            // and if it is the last one acquire and sum -- k = 0 .. ks-1 in order, whichever workgroup does it: same bits every run
+            // (the "I am last" flag lives in the kernel's one LDS array: a second __shared__ object can cost the K loop its
+            // counted waits -- cdna_hip_programming.md, three .s-level traps (a))
+            volatile int& s_last = *reinterpret_cast<volatile int*>(&red[0][0][0][0]);
+            const int ks = bid_.gz;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-through stores above have been acknowledged
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int* cnt = xf.tk_count + (tile_id * bid_.gy + bid_.y);
+                const int old = atomicAdd(cnt, 1);
+                const int lastv = old == ks - 1;
+                s_last = lastv;
+                if (lastv) atomicExch(cnt, 0);                      // left zero for the next launch that uses the counters
+            }
+            __syncthreads();
+            const bool last = s_last != 0;
+            __syncthreads();                                           // (red is reused below)
+            if (!last) return;
+            constexpr int NVT = TZ * TY * TX, G8 = COB * 2;          // voxels of the tile, 8-channel groups of this workgroup
+            static_assert(NT % G8 == 0, "a thread keeps its channel group");
+            const int grp = threadIdx.x % G8, ch0 = cobBase * 16 + grp * 8;
+            float bv8[8], s1[8], s2[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { bv8[i] = bias ? bias[ch0 + i] : 0.f; s1[i] = s2[i] = 0.f; }
+            for (int idx = threadIdx.x; idx < NVT * G8; idx += NT) {
+                const int vox = idx / G8;
+                const int vx = vox % TX, vy = (vox / TX) % TY, vz = vox / (TX * TY);
+                const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+                if (gz >= D || gy >= H || gx >= W) continue;
+                const int64_t row = (((int64_t)n * D + gz) * H + gy) * W + gx;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = bv8[i];
+                // four k's requested at a time (a counted loop of dependent round trips cost 35 us per launch); added in k order
+                for (int k0 = 0; k0 < ks; k0 += 4) {
+                    f32x4 u[4], w4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        u[j] = w4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (k0 + j < ks) {           // loads that bypass this XCD's L2 (agent-coherent), no acquire fence
+                            const float* pq = part + ((int64_t)(k0 + j) * Mtot + row) * CoutTotal + ch0;
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(u[j]) : "v"(pq) : "memory");
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w4[j]) : "v"(pq + 4) : "memory");
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]) :: "memory");
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (k0 + j < ks) {
+                            v[0] += u[j][0]; v[1] += u[j][1]; v[2] += u[j][2]; v[3] += u[j][3];
+                            v[4] += w4[j][0]; v[5] += w4[j][1]; v[6] += w4[j][2]; v[7] += w4[j][3];
+                        }
+                }
+                bf16x8 o;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { o[i] = (bf16)v[i]; const float q = (float)o[i]; s1[i] += q; s2[i] = fmaf(q, q, s2[i]); }
+                *reinterpret_cast<bf16x8*>(y + row * ycs + ch0) = o;
+            }
+            // lanes of one channel group (lane % G8) -> wave total -> the 8 waves in fixed order
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+#pragma unroll
+                for (int o_ = G8; o_ < 64; o_ <<= 1) { s1[i] += __shfl_xor(s1[i], o_, 64); s2[i] += __shfl_xor(s2[i], o_, 64); }
+            }
+            __syncthreads();                                           // (the K loop's LDS reads are long done; red is free)
+            if (lane < G8) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    red[wave][(lane * 8 + i) / 16][(lane * 8 + i) % 16][0] = s1[i];
+                    red[wave][(lane * 8 + i) / 16][(lane * 8 + i) % 16][1] = s2[i];
+                }
+            }
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < COB * 16 * 2; idx += NT) {
+                const int k = idx & 1, ch = idx >> 1;
+                float v = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < 8; w_++) v += red[w_][ch / 16][ch % 16][k];
+                xf.tk_rows[((int64_t)bid_.x * 2 + k) * CoutTotal + cobBase * 16 + ch] = v;
+            }
+            return;
+        }
     }
     float s1[COB][4], s2[COB][4];
 #pragma unroll
@@ -1338,10 +1431,23 @@ __global__ __launch_bounds__(BLK) void splitk_finish_kernel(const float* __restr
 template <int TZ, int TYB, int TXB, int BX, int COB>
 int launch_cfg(const bf16* x, int xcs, int Cin, const bf16* wp, const float* bias, bf16* y, int ycs, int Cout, Geo g,
                float* part, int ksplit, float* skws, hipStream_t s, bool defer_finish = false, int relu = 0,
-               const XfArgs* xf = nullptr) {
+               const XfArgs* xf = nullptr, float* tk_rows = nullptr, int* tk_count = nullptr) {
     constexpr int TY = TYB * (16 / BX), TX = TXB * BX;
     int tz = cdiv(g.D, TZ), ty = cdiv(g.H, TY), tx = cdiv(g.W, TX);
     dim3 grid((unsigned)(g.N * tz * ty * tx), (unsigned)(Cout / (16 * COB)), (unsigned)ksplit);
+    if (tk_rows) {       // split-K launch that finishes itself (ticket per (tile, output group)); eight-wave kernel only
+        MI3D_CHECK_ARG(ksplit > 1 && tk_count && mi3d_routes().conv8 != 0 && (!xf || xf->mode == 0) &&
+                       (int64_t)grid.x * grid.y <= CONV3_TK_COUNTERS && ycs % 8 == 0 && ((uintptr_t)y % 16) == 0,
+                       "conv3_mfma: this launch cannot take the split-K ticket");
+        XfArgs xa;
+        xa.tk_rows = tk_rows; xa.tk_count = tk_count;
+        constexpr size_t lds_tk = conv8_lds(TY, TX, COB);
+        MI3D_SET_MAX_LDS_ONCE((&conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, false, true, 0, true>), lds_tk + CONV8_XF_LDS);
+        conv3_mfma8_kernel<TZ, TYB, TXB, BX, COB, false, true, 0, true><<<grid, 512, lds_tk, s>>>(x, xcs, Cin, wp, bias, y, ycs, Cout, g.D, g.H, g.W,
+                                                                                                tz, ty, tx, skws, 0, xa);
+        MI3D_LAUNCH_CHECK();
+        return 0;
+    }
     // eight-wave variant (see conv3_mfma8_kernel); MI3D_CONV8=0 selects the four-wave kernels
     static_assert((TYB * TXB) % 2 == 0, "tile shapes used here have an even number of M-blocks per slice");
     const bool w8 = mi3d_routes().conv8 != 0;
@@ -1479,10 +1585,18 @@ bool conv3_mfma_xform_ok(int Cin, int Cout, Geo g) {
     return !big_geo(g) && !persist_ok(Cin, Cout, g) && Cout % 32 == 0 && Cin % 16 == 0 && Cin <= 256 && mi3d_routes().conv8 != 0;
 }
 
+bool conv3_mfma_ticket_ok(int Cin, int Cout, Geo g) {
+    if (!mi3d_routes().splitk_ticket || mi3d_routes().conv8 == 0 || big_geo(g) || persist_ok(Cin, Cout, g)) return false;
+    if (pick_ksplit(Cin, Cout, g) <= 1) return false;
+    const int64_t wgs = (int64_t)g.N * cdiv(g.D, 4) * cdiv(g.H, 8) * cdiv(g.W, 8) * (Cout / (Cout % 32 == 0 ? 32 : 16));
+    return wgs <= CONV3_TK_COUNTERS;
+}
+
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout, Geo g,
                    float* part, float* skws, hipStream_t s, Halves xh, Halves yh, int* ks_deferred, int relu, int ks_target,
-                   const XfArgs* xf) {
+                   const XfArgs* xf, float* tk_rows, int* tk_count) {
     if (ks_deferred) *ks_deferred = 0;
+    MI3D_CHECK_ARG(!tk_rows || (conv3_mfma_ticket_ok(Cin, Cout, g) && skws && ks_target == 0), "conv3_mfma_fwd: no split-K ticket for %d->%d here", Cin, Cout);
     MI3D_CHECK_ARG(!xf || xf->mode == 0 || conv3_mfma_xform_ok(Cin, Cout, g), "conv3_mfma_fwd: no apply-on-load kernel for %d->%d here", Cin, Cout);
     MI3D_CHECK_ARG((!xh.on() && !yh.on()) || persist_ok(Cin, Cout, g), "conv3_mfma_fwd: planar halves need the persistent kernel");
     MI3D_CHECK_ARG(conv3_mfma_supported(Cin, Cout, xcs, ycs), "conv3_mfma_fwd: unsupported channels %d->%d", Cin, Cout);
@@ -1540,6 +1654,10 @@ int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float*
         // input tile staged twice -- measured slower: forward 98 -> 114 us/step, input gradients 80 -> 93; profiles/r04_experiments_misc.txt)
         if (two) return launch_cfg<4, 8, 1, 16, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s, false, relu);
         return launch_cfg<4, 8, 1, 16, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, part, 1, nullptr, s, false, relu);
+    }
+    if (tk_rows) {      // the launch finishes its split-K sums and the BatchNorm partial rows itself (nothing deferred)
+        if (two) return launch_cfg<4, 2, 2, 4, 2>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, nullptr, ks, skws, s, false, 0, nullptr, tk_rows, tk_count);
+        return launch_cfg<4, 2, 2, 4, 1>(xp, xcs, Cin, w, bias, yp, ycs, Cout, g, nullptr, ks, skws, s, false, 0, nullptr, tk_rows, tk_count);
     }
     bool defer = ks > 1 && ks_deferred;
     if (defer) *ks_deferred = ks;

@@ -36,7 +36,7 @@ int conv3_mfma_pack(const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dg
 // scale (conv3 only, may be NULL): per-output-channel factor folded into the FORWARD image (inference: BatchNorm scale)
 struct PackJob { const float* w; void* a; void* b; int Cin, Cout, kind, mode_f, mode_d, blk0; const float* scale; };   // kind 0 conv3, 1 upconv
 constexpr int MAX_PACK_JOBS = 32;
-struct PackJobs { int n, nblocks; PackJob j[MAX_PACK_JOBS]; };
+struct PackJobs { int n, nblocks; PackJob j[MAX_PACK_JOBS]; int* zero = nullptr; int nzero = 0; };      // zero: ints block 0 clears (split-K ticket counters)
 int pack_all_add_conv3(PackJobs& J, const float* w, int Cin, int Cout, void* wp_fwd, void* wp_dgrad, Geo g,
                        const float* scale = nullptr);
 int pack_all_add_upconv(PackJobs& J, const float* w, int Cin, int Cout, void* wp);
@@ -68,11 +68,21 @@ struct XfArgs {
     float* dgamma = nullptr; float* dbeta = nullptr; int accumulate = 0;
     const float* drop = nullptr;                 // [N][C] Dropout3d scales or NULL
     bf16* side = nullptr; int side_cs = 0;
+    // split-K ticket (round 4, conv3_mfma8_kernel<..., TK>): per (tile, output group) arrival counters (zero before the launch, left
+    // zero by it) and the BatchNorm partial rows [tiles][2][Cout] the finishing workgroups write
+    float* tk_rows = nullptr; int* tk_count = nullptr;
 };
+// The split-K forward launch of this layer can finish itself: the LAST of the ks workgroups of an (output tile, channel group) to
+// arrive (one atomic ticket per workgroup on a counter only those ks workgroups touch) sums the ks fp32 partials in k order, adds
+// the bias, stores bf16 y and writes the tile's BatchNorm partial row -- the bn_stats_splitk launch of the layer disappears and
+// the consumer finishes <= 108 tile rows instead of 128 block rows.  Same bits in y as the separate finishing pass.
+bool conv3_mfma_ticket_ok(int Cin, int Cout, Geo g);
+constexpr int CONV3_TK_COUNTERS = 4096;         // ints of counter space a plan reserves
 bool conv3_mfma_xform_ok(int Cin, int Cout, Geo g);           // the launch conv3_mfma_fwd(Cin, Cout, g) would make can take XfArgs
 int conv3_mfma_fwd(const void* x, int xcs, int Cin, const void* wp, const float* bias, void* y, int ycs, int Cout,
                    Geo g, float* part, float* skws, hipStream_t s, Halves xh = Halves(), Halves yh = Halves(),
-                   int* ks_deferred = nullptr, int relu = 0, int ks_target = 0, const XfArgs* xf = nullptr);
+                   int* ks_deferred = nullptr, int relu = 0, int ks_target = 0, const XfArgs* xf = nullptr,
+                   float* tk_rows = nullptr, int* tk_count = nullptr);
 // ks_target > 0: split-K workgroup target of this launch (0 = the forward default).  The input-gradient convs of the backward
 // use conv3_bwd_ks_target() in the fused launch AND when they run stand-alone, so both routes produce the same bits
 int conv3_bwd_ks_target();

@@ -64,7 +64,7 @@ struct Plan {
         return h;
     }
     size_t gz[MAXL + 1], gcat[MAXL], gp[MAXL], sB, sB2, sC;
-    size_t bnws, wgws, wgws2, wgws3, statpart, skws;
+    size_t bnws, wgws, wgws2, wgws3, statpart, skws, tkcount;
     // (block, half) after whose BatchNorm backward the pending deferred weight gradients of group 1 / 2 go to the aux stream
     int flush_b[2], flush_h[2];
     size_t wgws_floats;
@@ -190,6 +190,7 @@ int build_plan(const mi3d_unet_desc* d, Plan& p) {
     p.sC = take(maxCM * p.esz);
     p.bnws = take(bn_ws_floats(maxC) * sizeof(float));
     p.statpart = take(statpart_floats * sizeof(float));
+    p.tkcount = take((size_t)CONV3_TK_COUNTERS * sizeof(int));        // split-K ticket counters (zeroed by the forward's pack launch)
     p.skws = take(skws_floats * sizeof(float));
     p.wgws_floats = wg_floats;
     p.wgws = take(wg_floats * sizeof(float));
@@ -230,6 +231,7 @@ struct Ctx {
     mutable int ndq = 0, nfork = 0;
     mutable bool aux_used = false;
     mutable bool packed = false;      // weight packs already done by the one-launch pack_all
+    mutable bool tk_zeroed = false;   // this call's pack launch cleared the split-K ticket counters
     // training & 4: another forward runs beside this one on a second stream (DANN source || target): the wide BatchNorm consumers
     // (whole-CU 1024-thread workgroups) get in each other's way there (+45 us/step measured); thin consumers + finalize launches
     mutable bool beside = false;
@@ -316,11 +318,14 @@ int block_forward(const Ctx& c, int b, const float* x, void* const* buffers, con
             // training: a split-K launch leaves its finishing pass to the statistics kernel (ksd = split factor).  (Deep levels
             // WITHOUT split-K -- conv with fused partial sums -> apply, two launches instead of three -- measured +0.10 ms in
             // round 2: the 8-16-chunk K loops on 32-216 workgroups cost more than the launch they save; that route is gone.)
+            // round 4: a split-K launch of a training forward finishes itself behind a per-tile ticket (y, BatchNorm partial rows)
+            const bool tk = training && c.tk_zeroed && !(h == 1 && xfa.mode) && conv3_mfma_ticket_ok(H.Cin, H.Cout, g);
             MI3D_TRY(conv3_mfma_fwd(in, ics, H.Cin, c.at(H.wpf), c.P(H.pidx + 1), c.at(H.y), H.Cout, H.Cout, g,
                                     training ? c.at<float>(p.statpart) : nullptr, c.at<float>(p.skws), c.s,
                                     (h == 0 && b > p.L) ? p.halves(B.level) : Halves(), Halves(), training ? &ksd : nullptr, 0, 0,
-                                    (h == 1 && xfa.mode) ? &xfa : nullptr));
-            fused_stats = training && conv3_mfma_fuses_stats(H.Cin, H.Cout, g);
+                                    (h == 1 && xfa.mode) ? &xfa : nullptr, tk ? c.at<float>(p.statpart) : nullptr,
+                                    tk ? c.at<int>(p.tkcount) : nullptr));
+            fused_stats = training && (tk || conv3_mfma_fuses_stats(H.Cin, H.Cout, g));
         } else if (p.dt == MI3D_BF16 && idt == MI3D_F32 && H.Cin == 1 && H.Cout % 16 == 0 && !mi3d_routes().force_direct &&
                    !mi3d_routes().no_c1_mfma) {
             // first layer on the matrix cores (taps are the K dimension), BN partial sums fused like the other convs
@@ -655,10 +660,11 @@ static LossCfg cfg_of(const mi3d_loss_cfg* c) {
 }
 
 // MFMA weight images of the DoubleConv blocks [b0, b1) (+ the transposed convs) of the training forward / backward, one launch
-static int pack_training_weights(const Ctx& c, int b0, int b1, bool upconvs) {
+static int pack_training_weights(const Ctx& c, int b0, int b1, bool upconvs, bool zero_tickets = false) {
     const Plan& p = c.p;
     PackJobs J;
     J.n = 0; J.nblocks = 0;
+    if (zero_tickets) { J.zero = c.at<int>(p.tkcount); J.nzero = CONV3_TK_COUNTERS; }
     for (int b = b0; b < b1 && b < p.nblk; b++)
         for (int h = 0; h < 2; h++) {
             const HalfP& H = p.blk[b].h[h];
@@ -669,6 +675,7 @@ static int pack_training_weights(const Ctx& c, int b0, int b1, bool upconvs) {
             int l = p.L - 1 - i;
             if (p.up_mfma[i]) MI3D_TRY(pack_all_add_upconv(J, c.P(p.up_pidx(i)), 2 * p.C[l], p.C[l], c.at(p.upw[i])));
         }
+    if (zero_tickets && J.n > 0) c.tk_zeroed = true;      // (pack_all_launch launches nothing for an empty job list)
     return pack_all_launch(J, c.s);
 }
 
@@ -707,7 +714,7 @@ static int unet_forward_impl(const mi3d_unet_desc* d, const float* x, const void
         MI3D_TRY(ncdhw_to_ndhwc(p.dt, x, c.at(p.xcl), d->in_channels, d->in_channels, d->N, p.geo[0].V(), c.s));
     // every MFMA weight pack of the network in one launch (prepacked_from = k > 0: the caller's mi3d_unet_pack_from already did
     // the blocks >= k and the transposed convs behind its optimizer update)
-    MI3D_TRY(pack_training_weights(c, 0, d->prepacked_from > 0 ? d->prepacked_from : p.nblk, d->prepacked_from <= 0));
+    MI3D_TRY(pack_training_weights(c, 0, d->prepacked_from > 0 ? d->prepacked_from : p.nblk, d->prepacked_from <= 0, training != 0));
     c.packed = true;
     for (int l = 0; l < L; l++) {
         // fused apply + pool: even sides (every voxel in exactly one window) and 32-bit element indices

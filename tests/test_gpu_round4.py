@@ -229,3 +229,50 @@ def test_cu_masked_aux_stream_is_bitwise_the_unmasked_one():
     for a, b in zip(o0, o1):
         assert torch.equal(a, b)
     assert torch.equal(g0, g1) and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("size,p_drop", [(96, 0.0), (64, 0.3)])
+def test_split_k_ticket_finishes_the_deep_forward_convs(routes, size, p_drop):
+    """Round 4: a split-K forward conv of a training step (levels 3-4, models/unet.py:11,15 of encoder.3 / bottleneck / decoder.0)
+    finishes itself -- the last of a tile's ks workgroups to take its ticket sums the fp32 partials in k order, stores bf16 y and
+    writes the tile's BatchNorm partial row -- instead of a bn_stats_splitk launch.  (1) Whichever workgroup arrives last, the
+    sums run in the same order: two independent runs are BITWISE equal (a missed release / acquire or a counter left non-zero
+    would show here).  (2) Against the separate finishing pass: the first such layer sees identical inputs and produces the same
+    y, so its batch statistics agree to fp32 roundoff (another partition of the same sum); everything downstream to bf16
+    re-rounding noise."""
+    x, y = synth(2, size, 782, blocky=True)
+
+    def run(mode):
+        routes.set("splitk_ticket", mode)
+        torch.manual_seed(0)
+        m = UNet3D(in_channels=1, out_channels=4, dropout_rate=p_drop).to(DEV).train()
+        ts = TrainStep(m, loss="combined", lr=lr, weight_decay=0.01, compute_dtype=torch.bfloat16, use_graph=False)
+        ts.load_batch(x.to(DEV), y.to(DEV))
+        outs = [ts.step_static().clone().cpu() for _ in range(6)]
+        torch.cuda.synchronize()
+        r = (outs, ts.arena.g.clone().cpu(), ts.arena.p.clone().cpu(), {k: b.clone().cpu() for k, b in m.named_buffers()})
+        ts.close()
+        return r
+
+    lr = 1e-3
+    a, b = run(1), run(1)
+    for u, v in zip(a[0], b[0]):
+        assert torch.equal(u, v)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    lr = 0.0                   # the comparison of the two routes: parameters fixed, so that only the kernels differ
+    a, c = run(1), run(0)
+    routes.reset("splitk_ticket")
+    first = "encoder.3.double_conv.1." if size == 96 else None      # first split-K layer at 96^3 (identical inputs on both routes)
+    # vs the finishing pass: first step's metrics, then the buffers after three steps
+    assert abs(float(a[0][0][0]) - float(c[0][0][0])) < 2e-3 * abs(float(c[0][0][0])), (a[0][0], c[0][0])
+    assert (a[0][0][1:] - c[0][0][1:]).abs().max() < 2e-3
+    for k in a[3]:
+        if "num_batches_tracked" in k:
+            assert torch.equal(a[3][k], c[3][k]), k
+        elif first and k.startswith(first):
+            assert relerr(a[3][k], c[3][k]) < 1e-6, (k, relerr(a[3][k], c[3][k]))
+        else:
+            assert relerr(a[3][k], c[3][k]) < 5e-3, (k, relerr(a[3][k], c[3][k]))
+    assert relerr(a[1], c[1]) < 5e-2, relerr(a[1], c[1])
