@@ -276,3 +276,27 @@ def test_split_k_ticket_finishes_the_deep_forward_convs(routes, size, p_drop):
         else:
             assert relerr(a[3][k], c[3][k]) < 5e-3, (k, relerr(a[3][k], c[3][k]))
     assert relerr(a[1], c[1]) < 5e-2, relerr(a[1], c[1])
+
+
+def test_split_k_ticket_is_stable_over_many_steps():
+    """The ticket's hand-off (write-through partial stores -> relaxed agent-scope ticket -> sc1 loads by the last arriver) under
+    repetition: with lr = 0 and a fixed batch every step is the same computation, so 150 consecutive steps (900 ticket launches,
+    ~50 000 tile episodes with whichever workgroup happens to arrive last) must return bitwise the same metrics and leave bitwise
+    the same gradients.  A stale read or a lost arrival shows up as a different loss."""
+    torch.manual_seed(0)
+    m = UNet3D(in_channels=1, out_channels=4, dropout_rate=0.0).to(DEV).train()
+    ts = TrainStep(m, loss="combined", lr=0.0, weight_decay=0.0, compute_dtype=torch.bfloat16, use_graph=False)
+    x, y = synth(2, 96, 783, blocky=True)
+    ts.load_batch(x.to(DEV), y.to(DEV))
+    ref = ts.step_static().clone()
+    g0 = ts.arena.g.clone()
+    bad = 0
+    for i in range(150):
+        o = ts.step_static()
+        if not torch.equal(o, ref):
+            bad += 1
+        if i % 50 == 49 and not torch.equal(ts.arena.g, g0):
+            bad += 1
+    torch.cuda.synchronize()
+    ts.close()
+    assert bad == 0, bad
